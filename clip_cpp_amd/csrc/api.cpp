@@ -1,0 +1,497 @@
+// api.cpp — the extern "C" boundary: every symbol of include/clip.h (= reference clip.h:42-109) plus
+// the MI355X extensions of include/clip_amd.h.  Thin shim: argument checking, host<->HBM staging,
+// then forward.cpp.  Nothing here throws across the ABI.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/clip_amd.h"
+#include "model.h"
+
+using namespace clipamd;
+
+namespace {
+
+int default_device() {
+    const char * e = getenv("CLIP_AMD_DEVICE");
+    if (!e || !*e) e = getenv("LOCAL_RANK");
+    if (e && *e) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0) return atoi(e) % n;
+        (void)hipGetLastError();
+    }
+    return 0;
+}
+
+// RAII device buffer for the test hooks
+struct DBuf {
+    void * p = nullptr;
+    explicit DBuf(size_t n) { if (hipMalloc(&p, n ? n : 16) != hipSuccess) p = nullptr; }
+    ~DBuf() { if (p) (void)hipFree(p); }
+};
+
+std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+
+}  // namespace
+
+extern "C" {
+
+// ---- ggml timing shim (include/ggml/ggml.h) ----
+void ggml_time_init(void) { g_t0 = std::chrono::steady_clock::now(); }
+int64_t ggml_time_us(void) {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g_t0).count();
+}
+int64_t ggml_time_ms(void) { return ggml_time_us() / 1000; }
+
+// ---- model lifetime ----
+struct clip_ctx * clip_model_load(const char * fname, const int verbosity) {
+    if (!fname) return nullptr;
+    return load_model(fname, verbosity, default_device());
+}
+struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int device) {
+    if (!fname) return nullptr;
+    return load_model(fname, verbosity, device);
+}
+void clip_free(struct clip_ctx * ctx) { free_model(ctx); }
+struct clip_text_hparams * clip_get_text_hparams(struct clip_ctx * ctx) { return &ctx->text_hparams; }
+struct clip_vision_hparams * clip_get_vision_hparams(struct clip_ctx * ctx) { return &ctx->vision_hparams; }
+
+int clip_amd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int clip_amd_ctx_device(const struct clip_ctx * ctx) { return ctx ? ctx->device : -1; }
+void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream) {
+    if (!ctx || ctx->device < 0) return;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+}
+void clip_amd_synchronize(struct clip_ctx * ctx) {
+    if (ctx && ctx->device >= 0) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+}
+
+// ---- tokenizer ----
+bool clip_tokenize(const struct clip_ctx * ctx, const char * text, struct clip_tokens * tokens) {
+    if (!ctx->has_text_encoder) {
+        printf("This GGUF file seems to have no text encoder\n");
+        return false;
+    }
+    std::vector<int32_t> v;
+    if (!tokenize_text(ctx, text, v)) return false;
+    tokens->size = v.size();
+    tokens->data = new clip_vocab_id[v.size()];   // caller-owned, as in the reference (clip.cpp:675)
+    std::copy(v.begin(), v.end(), tokens->data);
+    return true;
+}
+
+// ---- image containers ----
+struct clip_image_u8 * clip_image_u8_make() { return new clip_image_u8(); }
+struct clip_image_f32 * clip_image_f32_make() { return new clip_image_f32(); }
+void clip_image_u8_clean(struct clip_image_u8 * img) {
+    if (img && img->data) { delete[] img->data; img->data = nullptr; }
+}
+void clip_image_f32_clean(struct clip_image_f32 * res) {
+    if (res && res->data) { delete[] res->data; res->data = nullptr; }
+}
+void clip_image_u8_free(struct clip_image_u8 * img) { if (img) { clip_image_u8_clean(img); delete img; } }
+void clip_image_f32_free(struct clip_image_f32 * res) { if (res) { clip_image_f32_clean(res); delete res; } }
+
+bool clip_image_load_from_file(const char * fname, struct clip_image_u8 * img) { return load_image_file(fname, img); }
+bool clip_image_preprocess(const struct clip_ctx * ctx, const struct clip_image_u8 * img, struct clip_image_f32 * res) {
+    return preprocess_image(ctx, img, res);
+}
+void clip_image_batch_preprocess(const struct clip_ctx * ctx, const int n_threads, const struct clip_image_u8_batch * img_inputs,
+                                 struct clip_image_f32_batch * imgs_resized) {
+    imgs_resized->size = img_inputs->size;
+    const size_t n = img_inputs->size;
+    const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_threads), n));
+    if (nt == 1) {
+        for (size_t i = 0; i < n; i++) preprocess_image(ctx, &img_inputs->data[i], &imgs_resized->data[i]);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nt; t++)
+        pool.emplace_back([=]() {
+            for (size_t i = t; i < n; i += nt) preprocess_image(ctx, &img_inputs->data[i], &imgs_resized->data[i]);
+        });
+    for (auto & th : pool) th.join();
+}
+
+// ---- encoders: host-pointer forms (the reference API) ----
+bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_image_f32_batch * imgs, float * vec,
+                             const bool normalize) {
+    (void)n_threads;
+    clip_ctx * ctx = const_cast<clip_ctx *>(cctx);  // const handle, mutable workspace — as in the reference
+    if (!ctx->has_vision_encoder) {
+        printf("This gguf file seems to have no vision encoder\n");
+        return false;
+    }
+    if (ctx->device < 0) {
+        fprintf(stderr, "clip_image_batch_encode: no HIP device bound to this context — the encoders have no CPU fallback\n");
+        return false;
+    }
+    const int B = (int)imgs->size;
+    if (B <= 0) return true;
+    const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
+    const size_t per = (size_t)S * S * 3;
+    for (int b = 0; b < B; b++) {
+        if (imgs->data[b].nx != S || imgs->data[b].ny != S || !imgs->data[b].data) {
+            fprintf(stderr, "clip_image_batch_encode: image %d is %dx%d, expected %dx%d (run clip_image_preprocess first)\n", b,
+                    imgs->data[b].nx, imgs->data[b].ny, S, S);
+            return false;   // the reference GGML_ASSERTs here (clip.cpp:1293)
+        }
+    }
+    (void)hipSetDevice(ctx->device);
+    const int chunk = 256;
+    void * d_in = nullptr;
+    void * d_out = nullptr;
+    const int cmax = std::min(B, chunk);
+    if (hipMalloc(&d_in, per * 4 * cmax) != hipSuccess || hipMalloc(&d_out, (size_t)proj * 4 * cmax) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_in) (void)hipFree(d_in);
+        fprintf(stderr, "clip_image_batch_encode: out of device memory\n");
+        return false;
+    }
+    bool ok = true;
+    for (int b0 = 0; b0 < B && ok; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        for (int b = 0; b < Bc; b++)
+            ok = ok && hipMemcpyAsync((float *)d_in + per * b, imgs->data[b0 + b].data, per * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        ok = ok && vision_forward_device(ctx, (const float *)d_in, Bc, (float *)d_out, normalize);
+        ok = ok && hipMemcpyAsync(vec + (size_t)b0 * proj, d_out, (size_t)proj * 4 * Bc, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!ok) fprintf(stderr, "clip_image_batch_encode: HIP error: %s\n", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (ctx->profiling) prof_collect(ctx);
+    return ok;
+}
+
+bool clip_image_encode(const struct clip_ctx * ctx, const int n_threads, struct clip_image_f32 * img, float * vec, const bool normalize) {
+    if (!ctx->has_vision_encoder) {
+        printf("This gguf file seems to have no vision encoder\n");
+        return false;
+    }
+    clip_image_f32_batch b{};
+    b.size = 1;
+    b.data = img;
+    return clip_image_batch_encode(ctx, n_threads, &b, vec, normalize);
+}
+
+bool clip_amd_image_batch_encode_device(struct clip_ctx * ctx, const float * d_imgs, int batch, float * d_out, bool normalize) {
+    return vision_forward_device(ctx, d_imgs, batch, d_out, normalize);
+}
+
+bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_tokens * tokens, size_t n_texts, float * vec,
+                            const bool normalize) {
+    (void)n_threads;
+    clip_ctx * ctx = const_cast<clip_ctx *>(cctx);
+    if (!ctx->has_text_encoder) {
+        printf("This GGUF file seems to have no text encoder\n");
+        return false;
+    }
+    if (ctx->device < 0) {
+        fprintf(stderr, "clip_text_encode: no HIP device bound to this context — the encoders have no CPU fallback\n");
+        return false;
+    }
+    if (n_texts == 0) return true;
+    std::vector<int32_t> ids, off(n_texts + 1, 0);
+    for (size_t i = 0; i < n_texts; i++) {
+        if (!tokens[i].data || tokens[i].size == 0) { fprintf(stderr, "clip_text_encode: empty token list\n"); return false; }
+        for (size_t j = 0; j < tokens[i].size; j++) {
+            const int32_t id = tokens[i].data[j];
+            if (id < 0 || id >= ctx->text_hparams.n_vocab) { fprintf(stderr, "clip_text_encode: token id %d out of range\n", id); return false; }
+            ids.push_back(id);
+        }
+        off[i + 1] = (int32_t)ids.size();
+    }
+    (void)hipSetDevice(ctx->device);
+    const int proj = ctx->text_hparams.projection_dim;
+    DBuf d_ids(ids.size() * 4), d_out(n_texts * (size_t)proj * 4);
+    if (!d_ids.p || !d_out.p) { fprintf(stderr, "clip_text_encode: out of device memory\n"); return false; }
+    bool ok = hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && text_forward_device(ctx, (const int32_t *)d_ids.p, off.data(), (int)n_texts, (float *)d_out.p, normalize);
+    ok = ok && hipMemcpyAsync(vec, d_out.p, n_texts * (size_t)proj * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (ctx->profiling) prof_collect(ctx);
+    return ok;
+}
+
+bool clip_text_encode(const struct clip_ctx * ctx, const int n_threads, const struct clip_tokens * tokens, float * vec, const bool normalize) {
+    if (!ctx->has_text_encoder) {
+        printf("This GGUF file seems to have no text encoder\n");
+        return false;
+    }
+    return clip_text_batch_encode(ctx, n_threads, tokens, 1, vec, normalize);
+}
+
+bool clip_amd_text_batch_encode_device(struct clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets, int n_texts, float * d_out,
+                                       bool normalize) {
+    return text_forward_device(ctx, d_ids, h_offsets, n_texts, d_out, normalize);
+}
+
+// ---- scoring (host, exact reference semantics) ----
+float clip_similarity_score(const float * vec1, const float * vec2, const int vec_dim) {
+    float dot = 0.0f;   // sequential f32 accumulation, reference clip.cpp:1525-1532
+    for (int i = 0; i < vec_dim; i++) dot += vec1[i] * vec2[i];
+    return dot;
+}
+
+bool clip_compare_text_and_image(const struct clip_ctx * ctx, const int n_threads, const char * text, const struct clip_image_u8 * image,
+                                 float * score) {
+    if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
+        printf("clip_compare_text_and_image function can only be used with two-tower models\n");
+        return false;
+    }
+    const int dim = ctx->vision_hparams.projection_dim;
+    std::vector<float> img_vec(dim), txt_vec(dim);
+    std::vector<int32_t> ids;
+    if (!tokenize_text(ctx, text, ids)) return false;
+    clip_tokens tk{ids.data(), ids.size()};
+    if (!clip_text_encode(ctx, n_threads, &tk, txt_vec.data(), true)) return false;
+    clip_image_f32 res{};
+    if (!preprocess_image(ctx, image, &res)) return false;
+    const bool ok = clip_image_encode(ctx, n_threads, &res, img_vec.data(), true);
+    clip_image_f32_clean(&res);   // the reference leaks this temporary
+    if (!ok) return false;
+    *score = clip_similarity_score(img_vec.data(), txt_vec.data(), dim);
+    return true;
+}
+
+bool softmax_with_sorting(float * arr, const int length, float * sorted_scores, int * indices) {
+    if (length < 0) return false;
+    // exp(x) + 1e-9, no max-subtraction, sum in double (reference clip.cpp:1591-1622)
+    double sum = 0.0;
+    for (int i = 0; i < length; i++) {
+        arr[i] = (float)(exp(arr[i]) + 1e-9);
+        sum += arr[i];
+    }
+    std::vector<int> order(length);
+    for (int i = 0; i < length; i++) {
+        arr[i] = (float)(arr[i] / sum);
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return arr[a] > arr[b]; });
+    for (int i = 0; i < length; i++) {
+        sorted_scores[i] = arr[order[i]];
+        indices[i] = order[i];
+    }
+    return true;
+}
+
+bool clip_zero_shot_label_image(struct clip_ctx * ctx, const int n_threads, const struct clip_image_u8 * input_img, const char ** labels,
+                                const size_t n_labels, float * scores, int * indices) {
+    if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
+        printf("clip_zero_shot_label_image function can only be used with two-tower models\n");
+        return false;
+    }
+    const int dim = ctx->vision_hparams.projection_dim;
+    clip_image_f32 res{};
+    if (!preprocess_image(ctx, input_img, &res)) return false;
+    std::vector<float> img_vec(dim);
+    const bool iok = clip_image_encode(ctx, n_threads, &res, img_vec.data(), false);   // un-normalised, as the reference (:1639)
+    clip_image_f32_clean(&res);
+    if (!iok) return false;
+    // all labels in ONE batched text pass (the reference encodes them one by one, :1647-1653)
+    std::vector<std::vector<int32_t>> ids(n_labels);
+    std::vector<clip_tokens> toks(n_labels);
+    for (size_t i = 0; i < n_labels; i++) {
+        if (!tokenize_text(ctx, labels[i], ids[i])) return false;
+        toks[i] = clip_tokens{ids[i].data(), ids[i].size()};
+    }
+    std::vector<float> txt((size_t)n_labels * dim), sims(n_labels);
+    if (!clip_text_batch_encode(ctx, n_threads, toks.data(), n_labels, txt.data(), false)) return false;
+    for (size_t i = 0; i < n_labels; i++) sims[i] = clip_similarity_score(img_vec.data(), txt.data() + i * dim, dim);
+    return softmax_with_sorting(sims.data(), (int)n_labels, scores, indices);
+}
+
+// ---- quantizer (reference clip.cpp:1661-1844): re-emit the GGUF with 2-D "*weight" tensors quantised ----
+bool clip_model_quantize(const char * fname_inp, const char * fname_out, const int itype) {
+    switch (itype) {
+    case 2: case 3: case 6: case 7: case 8: break;
+    default:
+        fprintf(stderr, "%s: invalid quantization type %d\n", "clip_model_quantize", itype);
+        return false;
+    }
+    GgufFile g;
+    std::string err;
+    if (!g.open(fname_inp, err)) { fprintf(stderr, "clip_model_quantize: %s\n", err.c_str()); return false; }
+    std::vector<std::pair<std::string, GgufValue>> kv;
+    bool have_qv = false;
+    for (auto & e : g.kv) {
+        if (e.first == "general.file_type") { kv.emplace_back(e.first, gguf_make_u32((uint32_t)itype)); continue; }
+        if (e.first == "general.quantization_version") { kv.emplace_back(e.first, gguf_make_u32(2)); have_qv = true; continue; }
+        kv.push_back(e);
+    }
+    if (!have_qv) kv.emplace_back("general.quantization_version", gguf_make_u32(2));   // GGML_QNT_VERSION
+    std::vector<std::vector<uint8_t>> store(g.tensors.size());
+    std::vector<GgufOutTensor> outs;
+    size_t total_org = 0, total_new = 0;
+    std::vector<float> f32buf;
+    for (size_t i = 0; i < g.tensors.size(); i++) {
+        const GgufTensorInfo & t = g.tensors[i];
+        const std::string & name = t.name;
+        // regex ".*weight" (full match) and n_dims == 2   (reference clip.cpp:1711-1739)
+        bool quantize = name.size() >= 6 && name.compare(name.size() - 6, 6, "weight") == 0 && t.n_dims == 2;
+        GgufOutTensor o;
+        o.name = name;
+        o.n_dims = t.n_dims;
+        for (int d = 0; d < 4; d++) o.ne[d] = t.ne[d];
+        if (quantize) {
+            if (t.type != GT_F32 && t.type != GT_F16) { printf("Please use an input file in f32 or f16\n"); return false; }
+            if (t.ne[0] % 32) quantize = false;
+        }
+        if (quantize) {
+            const int64_t n = t.ne[0] * t.nrows();
+            f32buf.resize((size_t)n);
+            dequantize_row(t.type, t.data, f32buf.data(), n);
+            store[i].resize(ggml_row_bytes(itype, t.ne[0]) * (size_t)t.nrows());
+            quantize_rows(itype, f32buf.data(), store[i].data(), t.nrows(), t.ne[0]);
+            o.type = itype;
+            o.data = store[i].data();
+            o.nbytes = store[i].size();
+        } else {
+            o.type = t.type;
+            o.data = t.data;
+            o.nbytes = t.nbytes;
+        }
+        total_org += t.nbytes;
+        total_new += o.nbytes;
+        printf("%s: n_dims = %d | quantize=%d | size = %f MB -> %f MB\n", name.c_str(), t.n_dims, (int)quantize, t.nbytes / 1024.0 / 1024.0,
+               o.nbytes / 1024.0 / 1024.0);
+        outs.push_back(o);
+    }
+    if (!gguf_write(fname_out, g.version, g.alignment, kv, outs, err)) { fprintf(stderr, "clip_model_quantize: %s\n", err.c_str()); return false; }
+    printf("%s: original size  = %8.2f MB\n", "clip_model_quantize", total_org / 1024.0 / 1024.0);
+    printf("%s: quantized size  = %8.2f MB\n", "clip_model_quantize", total_new / 1024.0 / 1024.0);
+    return true;
+}
+
+// ---- profiling ----
+void clip_amd_profile_enable(struct clip_ctx * ctx, bool on) {
+    if (!ctx || ctx->device < 0) return;
+    if (!on) prof_collect(ctx);
+    ctx->profiling = on;
+}
+
+// Copies a textual report "tag launches total_ms flops bytes\n" into buf; returns bytes needed.
+int clip_amd_profile_report(struct clip_ctx * ctx, char * buf, int cap, bool reset) {
+    if (!ctx) return 0;
+    if (ctx->device >= 0) prof_collect(ctx);
+    std::string s;
+    char line[256];
+    for (auto & e : ctx->prof) {
+        snprintf(line, sizeof line, "%s %lld %.6f %.6e %.6e\n", e.first.c_str(), (long long)e.second.launches, e.second.ms, e.second.flops,
+                 e.second.bytes);
+        s += line;
+    }
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    if (reset) ctx->prof.clear();
+    return (int)s.size() + 1;
+}
+
+int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches, int cap, bool reset) {
+    if (!ctx) return 0;
+    if (ctx->device >= 0) prof_collect(ctx);
+    static const char * fam[4] = {"gemm", "attention", "layernorm", ""};
+    float m[4] = {0, 0, 0, 0};
+    int64_t l[4] = {0, 0, 0, 0};
+    for (auto & e : ctx->prof) {
+        int f = 3;
+        for (int i = 0; i < 3; i++)
+            if (e.first.compare(0, strlen(fam[i]), fam[i]) == 0) { f = i; break; }
+        m[f] += (float)e.second.ms;
+        l[f] += e.second.launches;
+    }
+    const int n = std::min(cap, 4);
+    for (int i = 0; i < n; i++) { ms[i] = m[i]; launches[i] = l[i]; }
+    if (reset) ctx->prof.clear();
+    return n;
+}
+
+// ---- kernel-level test hooks ----
+int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias, const float * resid,
+                       float * y, int epilogue, int tile) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); fprintf(stderr, "clip_amd_test_gemm: no HIP device\n"); return -1; }
+    // the weight goes through the production repack path (load.cpp)
+    DevWeight W;
+    void * wbase = nullptr;
+    if (!repack_for_test(type, w_raw, N, K, W, &wbase)) return -2;
+    const int Kpad = W.Kpad;
+    DBuf dx32((size_t)M * K * 4), dx16((size_t)(M + 1) * Kpad * 2), dbias((size_t)N * 4), dres((size_t)M * N * 4), dout((size_t)M * N * 4), dout32((size_t)M * N * 4);
+    int rc = 0;
+    hipStream_t s = nullptr;
+    (void)hipMemcpy(dx32.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice);
+    if (bias) (void)hipMemcpy(dbias.p, bias, (size_t)N * 4, hipMemcpyHostToDevice);
+    launch_f32_to_f16((const float *)dx32.p, (int)K, (half_t *)dx16.p, Kpad, (int)M, (int)K, Kpad, s);
+    GemmParams p;
+    p.A = (const half_t *)dx16.p; p.lda = Kpad; p.M = (int)M; p.W = W; p.bias = bias ? (const float *)dbias.p : nullptr; p.ldc = (int)N;
+    int epi = EPI_F32;
+    switch (epilogue) {
+    case 0: epi = EPI_F32; p.out = dout32.p; break;
+    case 1: epi = EPI_F16; p.out = dout.p; p.qscale = 1.0f; p.qcols = 0; break;
+    case 2: epi = EPI_GELU_F16; p.out = dout.p; break;
+    case 3: epi = EPI_QGELU_F16; p.out = dout.p; break;
+    case 4:
+        epi = EPI_RESID_F32;
+        (void)hipMemcpy(dout32.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice);
+        p.out = dout32.p;
+        p.resid = (const float *)dout32.p;
+        break;
+    default: rc = -3;
+    }
+    if (rc == 0) {
+        launch_gemm(p, epi, tile, s);
+        if (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16)
+            launch_f16_to_f32((const half_t *)dout.p, (int)N, (float *)dout32.p, (int)N, (int)M, (int)N, s);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = -4;
+        else (void)hipMemcpy(y, dout32.p, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(wbase);
+    return rc;
+}
+
+int clip_amd_test_layernorm(const float * x, const float * w, const float * b, float eps, int64_t rows, int64_t h, float * y, int out_f16) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return -1; }
+    DBuf dx((size_t)rows * h * 4), dw((size_t)h * 4), db((size_t)h * 4), dy((size_t)rows * h * 4), dh_((size_t)rows * h * 2);
+    (void)hipMemcpy(dx.p, x, (size_t)rows * h * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dw.p, w, (size_t)h * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db.p, b, (size_t)h * 4, hipMemcpyHostToDevice);
+    if (out_f16) {
+        launch_layernorm((const float *)dx.p, (int)h, nullptr, 1, (const float *)dw.p, (const float *)db.p, eps, (int)rows, (int)h, (half_t *)dh_.p, (int)h, nullptr, 0, nullptr);
+        launch_f16_to_f32((const half_t *)dh_.p, (int)h, (float *)dy.p, (int)h, (int)rows, (int)h, nullptr);
+    } else {
+        launch_layernorm((const float *)dx.p, (int)h, nullptr, 1, (const float *)dw.p, (const float *)db.p, eps, (int)rows, (int)h, nullptr, 0, (float *)dy.p, (int)h, nullptr);
+    }
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return -4;
+    (void)hipMemcpy(y, dy.p, (size_t)rows * h * 4, hipMemcpyDeviceToHost);
+    return 0;
+}
+
+int clip_amd_test_attention(const float * qkv, int nseq, int T, int h, int n_head, int causal, float * out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return -1; }
+    const size_t rows = (size_t)nseq * T;
+    DBuf d32(rows * 3 * h * 4), d16(rows * 3 * h * 2), o16(rows * h * 2), o32(rows * h * 4);
+    (void)hipMemcpy(d32.p, qkv, rows * 3 * h * 4, hipMemcpyHostToDevice);
+    launch_f32_to_f16((const float *)d32.p, 3 * h, (half_t *)d16.p, 3 * h, (int)rows, 3 * h, 3 * h, nullptr);
+    if (!launch_attention((const half_t *)d16.p, (half_t *)o16.p, nseq, T, nullptr, T, h, n_head, causal != 0, nullptr)) return -2;
+    launch_f16_to_f32((const half_t *)o16.p, h, (float *)o32.p, h, (int)rows, h, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return -4;
+    (void)hipMemcpy(out, o32.p, rows * h * 4, hipMemcpyDeviceToHost);
+    return 0;
+}
+
+}  // extern "C"

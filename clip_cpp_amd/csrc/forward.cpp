@@ -1,0 +1,317 @@
+// forward.cpp — the ViT / text-transformer forward pass as a sequence of HIP kernel launches.
+//
+// Follows, step for step, the graphs that reference clip.cpp builds for ggml:
+//   vision: clip_image_batch_encode, clip.cpp:1247-1523 (step table in SURVEY §3.3)
+//   text  : clip_text_encode,        clip.cpp:1016-1233
+// with these MI355X-side fusions: HWC->CHW pack + im2col in one kernel; patch GEMM epilogue writes
+// straight into the token-major residual stream and adds the position embedding; q/k/v are one GEMM
+// whose epilogue applies bias and the 1/sqrt(d_head) Q scale; attention is one fused kernel; bias +
+// GELU and bias + residual live in GEMM epilogues; LayerNorm emits the fp16 operand of the next GEMM.
+// Residual stream: f32 [rows][h] in HBM for the whole pass (as in ggml).  7 launches per layer.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "model.h"
+
+namespace clipamd {
+
+namespace {
+
+struct Carver {
+    uint8_t * base;
+    size_t off = 0;
+    explicit Carver(void * b) : base((uint8_t *)b) {}
+    template <typename T> T * take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T * p = base ? (T *)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct ProfScope {
+    clip_ctx * ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+    std::string tag;
+    double flops, bytes;
+    ProfScope(clip_ctx * c, const char * family, long m, long n, long k, double fl, double by) : ctx(c), on(c->profiling), flops(fl), bytes(by) {
+        if (!on) return;
+        char buf[96];
+        snprintf(buf, sizeof buf, "%s:%ldx%ldx%ld", family, m, n, k);
+        tag = buf;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({a, b, tag, flops, bytes});
+    }
+};
+
+double weight_bytes(const DevWeight & W) {
+    const double nblk = (double)(W.K / 32) * W.N;
+    switch (W.wtype) {
+    case W_F16: return (double)W.N * W.K * 2;
+    case W_Q4_0: return nblk * 18;
+    case W_Q4_1: return nblk * 20;
+    case W_Q5_0: return nblk * 22;
+    case W_Q5_1: return nblk * 24;
+    case W_Q8_0: return nblk * 34;
+    }
+    return 0;
+}
+
+void gemm(clip_ctx * ctx, const char * what, const GemmParams & p, int epi) {
+    const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
+    const double by = weight_bytes(p.W) + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : 4);
+    ProfScope ps(ctx, what, p.M, p.W.N, p.W.K, fl, by);
+    launch_gemm(p, epi, 0, ctx->stream);
+}
+
+// L x { LN1, QKV, attention, out-proj(+res), LN2, FFN-up(+act), FFN-down(+res) }   (clip.cpp:1342-1423 / :1064-1143)
+bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
+                const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid) {
+    hipStream_t s = ctx->stream;
+    const int dh = h / nh;
+    const float qscale = 1.0f / sqrtf((float)dh);
+    const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    for (const DevLayer & l : tw.layers) {
+        {
+            ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
+            launch_layernorm(x, h, nullptr, 1, l.ln1_w, l.ln1_b, eps, rows, h, xn, h, nullptr, 0, s);
+        }
+        GemmParams p;
+        p.A = xn; p.lda = h; p.M = rows; p.W = l.qkv; p.bias = l.qkv_b; p.out = qkv; p.ldc = 3 * h;
+        p.qscale = qscale; p.qcols = h;   // Q = (W_q x + b_q) / sqrt(d_head): scale after bias (clip.cpp:1363)
+        gemm(ctx, "gemm_qkv", p, EPI_F16);
+        {
+            const double afl = 4.0 * (double)nseq * nh * (double)max_len * max_len * dh;
+            ProfScope ps(ctx, "attention", nseq * nh, max_len, dh, afl, (double)rows * h * 8);
+            if (!launch_attention(qkv, att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s)) {
+                fprintf(stderr, "clip (hip): attention kernel does not support T=%d d_head=%d\n", max_len, dh);
+                return false;
+            }
+        }
+        GemmParams po;
+        po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x;
+        gemm(ctx, "gemm_out", po, EPI_RESID_F32);
+        {
+            ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
+            launch_layernorm(x, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, rows, h, xn, h, nullptr, 0, s);
+        }
+        GemmParams p1;
+        p1.A = xn; p1.lda = h; p1.M = rows; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = mid; p1.ldc = ff;
+        gemm(ctx, "gemm_ffn_up", p1, act);
+        GemmParams p2;
+        p2.A = mid; p2.lda = ff; p2.M = rows; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = x; p2.ldc = h; p2.resid = x;
+        gemm(ctx, "gemm_ffn_down", p2, EPI_RESID_F32);
+    }
+    return true;
+}
+
+bool check_device(clip_ctx * ctx, const char * who) {
+    if (!ctx || ctx->device < 0) {
+        fprintf(stderr, "%s: no HIP device bound to this context — the encoders have no CPU fallback\n", who);
+        return false;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        fprintf(stderr, "%s: hipSetDevice(%d) failed\n", who, ctx->device);
+        return false;
+    }
+    return true;
+}
+
+bool launch_ok(const char * who) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fprintf(stderr, "%s: HIP launch error: %s\n", who, hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool ensure_workspace(clip_ctx * ctx, size_t bytes) {
+    if (ctx->ws.bytes >= bytes) return true;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws.base) (void)hipFree(ctx->ws.base);
+    ctx->ws.base = nullptr;
+    ctx->ws.bytes = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    if (hipMalloc(&ctx->ws.base, want) != hipSuccess) {
+        (void)hipGetLastError();
+        fprintf(stderr, "clip (hip): cannot allocate %zu MB of workspace\n", want >> 20);
+        return false;
+    }
+    ctx->ws.bytes = want;
+    return true;
+}
+
+bool ensure_pinned(clip_ctx * ctx, size_t bytes) {
+    if (ctx->pinned_bytes >= bytes) return true;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    if (hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    ctx->pinned_bytes = bytes;
+    return true;
+}
+
+void prof_collect(clip_ctx * ctx) {
+    if (ctx->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto & p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ProfEntry & e = ctx->prof[p.tag];
+            e.ms += ms;
+            e.launches += 1;
+            e.flops += p.flops;
+            e.bytes += p.bytes;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    ctx->pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
+    if (!check_device(ctx, "clip_image_batch_encode")) return false;
+    if (!ctx->has_vision_encoder) {
+        printf("This gguf file seems to have no vision encoder\n");
+        return false;
+    }
+    if (B <= 0) return true;
+    const auto & hp = ctx->vision_hparams;
+    const DevTower & V = ctx->vision;
+    const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1;
+    const int h = hp.hidden_size, ff = hp.n_intermediate, nh = hp.n_head, proj = hp.projection_dim;
+    hipStream_t s = ctx->stream;
+
+    // images are processed in chunks so that the workspace stays bounded (<= ~6 GB even for ViT-H)
+    const size_t per_img = (size_t)T * ((size_t)h * 4 + (size_t)h * 2 * 2 + (size_t)3 * h * 2 + (size_t)ff * 2) + (size_t)Np * V.patch.Kpad * 2;
+    int chunk = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, ((size_t)6 << 30) / per_img));
+    chunk = std::min(chunk, 1024);
+
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        const int rows = Bc * T;
+        Carver sizer(nullptr);
+        auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& col,
+                         half_t *& pooled, float *& emb) {
+            x = c.take<float>((size_t)rows * h);
+            xn = c.take<half_t>((size_t)rows * h);
+            qkv = c.take<half_t>((size_t)rows * 3 * h);
+            att = c.take<half_t>((size_t)rows * h);
+            mid = c.take<half_t>((size_t)rows * ff);
+            col = c.take<half_t>((size_t)Bc * Np * V.patch.Kpad);
+            pooled = c.take<half_t>((size_t)Bc * h);
+            emb = c.take<float>((size_t)Bc * proj);
+        };
+        float *x, *emb;
+        half_t *xn, *qkv, *att, *mid, *col, *pooled;
+        carve(sizer, x, xn, qkv, att, mid, col, pooled, emb);
+        if (!ensure_workspace(ctx, sizer.off + 4096)) return false;
+        Carver c(ctx->ws.base);
+        carve(c, x, xn, qkv, att, mid, col, pooled, emb);
+
+        const float * imgs = d_imgs + (size_t)b0 * S * S * 3;
+        // patch embedding = im2col + GEMM (ggml_conv_2d, clip.cpp:1309-1312); epilogue scatters to token rows + pos
+        {
+            ProfScope ps(ctx, "im2col", Bc * Np, V.patch.Kpad, 0, 0, (double)Bc * S * S * 3 * 4 + (double)Bc * Np * V.patch.Kpad * 2);
+            launch_im2col(imgs, col, Bc, S, P, V.patch.Kpad, s);
+        }
+        GemmParams pp;
+        pp.A = col; pp.lda = V.patch.Kpad; pp.M = Bc * Np; pp.W = V.patch; pp.out = x; pp.ldc = h;
+        pp.Np = Np; pp.T = T; pp.pos = V.pos;
+        gemm(ctx, "gemm_patch", pp, EPI_PATCH_F32);
+        launch_cls_rows(x, V.class_embd, V.pos, Bc, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
+        {
+            ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 8);
+            launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);  // pre-LN (:1334-1339)
+        }
+        if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid)) return false;
+        // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
+        launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, pooled, h, nullptr, 0, s);
+        GemmParams pj;
+        pj.A = pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = emb; pj.ldc = proj;
+        gemm(ctx, "gemm_proj", pj, EPI_F32);   // projection, no bias (:1443)
+        launch_l2norm(emb, d_out + (size_t)b0 * proj, Bc, proj, normalize, s);  // (:1446-1455)
+        if (!launch_ok("clip_image_batch_encode")) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets, int n_texts, float * d_out,
+                         bool normalize) {
+    if (!check_device(ctx, "clip_text_encode")) return false;
+    if (!ctx->has_text_encoder) {
+        printf("This GGUF file seems to have no text encoder\n");
+        return false;
+    }
+    if (n_texts <= 0) return true;
+    const auto & hp = ctx->text_hparams;
+    const DevTower & Tw = ctx->text;
+    const int h = hp.hidden_size, ff = hp.n_intermediate, nh = hp.n_head, proj = hp.projection_dim;
+    hipStream_t s = ctx->stream;
+    const int rows = h_offsets[n_texts] - h_offsets[0];
+    int max_len = 0;
+    for (int i = 0; i < n_texts; i++) {
+        const int len = h_offsets[i + 1] - h_offsets[i];
+        if (len <= 0 || len > hp.num_positions) {
+            // the reference would index past position_embeddings here (clip.cpp:1054-1061); refuse instead
+            fprintf(stderr, "clip_text_encode: %d tokens is outside [1, %d]\n", len, hp.num_positions);
+            return false;
+        }
+        max_len = std::max(max_len, len);
+    }
+    auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& pooled,
+                     float *& emb, int *& seq, int *& last) {
+        x = c.take<float>((size_t)rows * h);
+        xn = c.take<half_t>((size_t)rows * h);
+        qkv = c.take<half_t>((size_t)rows * 3 * h);
+        att = c.take<half_t>((size_t)rows * h);
+        mid = c.take<half_t>((size_t)rows * ff);
+        pooled = c.take<half_t>((size_t)n_texts * h);
+        emb = c.take<float>((size_t)n_texts * proj);
+        seq = c.take<int>((size_t)n_texts + 1);
+        last = c.take<int>((size_t)n_texts);
+    };
+    float *x, *emb;
+    half_t *xn, *qkv, *att, *mid, *pooled;
+    int *seq, *last;
+    Carver sizer(nullptr);
+    carve(sizer, x, xn, qkv, att, mid, pooled, emb, seq, last);
+    if (!ensure_workspace(ctx, sizer.off + 4096)) return false;
+    Carver c(ctx->ws.base);
+    carve(c, x, xn, qkv, att, mid, pooled, emb, seq, last);
+    {
+        std::vector<int> hs(2 * (size_t)n_texts + 1);
+        for (int i = 0; i <= n_texts; i++) hs[i] = h_offsets[i] - h_offsets[0];
+        for (int i = 0; i < n_texts; i++) hs[n_texts + 1 + i] = hs[i + 1] - 1;   // last token row (EOS) — clip.cpp:1154-1155
+        (void)hipMemcpyAsync(seq, hs.data(), ((size_t)n_texts + 1) * 4, hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(last, hs.data() + n_texts + 1, (size_t)n_texts * 4, hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);
+    }
+    launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
+    if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
+    // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
+    launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+    GemmParams pj;
+    pj.A = pooled; pj.lda = h; pj.M = n_texts; pj.W = Tw.proj; pj.out = emb; pj.ldc = proj;
+    gemm(ctx, "gemm_proj", pj, EPI_F32);     // (:1160)
+    launch_l2norm(emb, d_out, n_texts, proj, normalize, s);  // (:1163-1166)
+    return launch_ok("clip_text_encode");
+}
+
+}  // namespace clipamd

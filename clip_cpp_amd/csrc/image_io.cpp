@@ -1,0 +1,233 @@
+// image_io.cpp — clip_image_load_from_file (reference clip.cpp:709-726, which delegates to the vendored
+// stb_image).  Host-side and outside the GPU hot path.  Own decoders, 3-channel RGB
+// output like stbi_load(..., 3): binary PNM (P5/P6), uncompressed 24/32-bit BMP, PNG (8/16-bit, all
+// colour types, non-interlaced and Adam7, inflate via zlib) and JPEG (jpeg_decode.cpp: baseline +
+// progressive Huffman).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+#include "model.h"
+
+namespace clipamd {
+
+bool decode_jpeg(const uint8_t * data, size_t size, std::vector<uint8_t> & rgb, int & nx, int & ny, std::string & err);  // jpeg_decode.cpp
+
+namespace {
+
+bool read_file(const char * fname, std::vector<uint8_t> & out) {
+    FILE * f = fopen(fname, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n <= 0) { fclose(f); return false; }
+    out.resize((size_t)n);
+    const bool ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+// ---- PNM ----
+bool decode_pnm(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
+    if (d.size() < 7 || d[0] != 'P' || (d[1] != '5' && d[1] != '6')) return false;
+    const int ch = d[1] == '6' ? 3 : 1;
+    size_t p = 2;
+    int vals[3], got = 0;
+    while (got < 3 && p < d.size()) {
+        if (d[p] == '#') { while (p < d.size() && d[p] != '\n') p++; continue; }
+        if (d[p] == ' ' || d[p] == '\t' || d[p] == '\n' || d[p] == '\r') { p++; continue; }
+        int v = 0, nd = 0;
+        while (p < d.size() && d[p] >= '0' && d[p] <= '9') { v = v * 10 + (d[p] - '0'); p++; nd++; }
+        if (!nd) return false;
+        vals[got++] = v;
+    }
+    if (got < 3 || p >= d.size()) return false;
+    p++;  // single whitespace after maxval
+    nx = vals[0]; ny = vals[1];
+    if (nx <= 0 || ny <= 0 || vals[2] != 255) return false;
+    const size_t need = (size_t)nx * ny * ch;
+    if (d.size() - p < need) return false;
+    rgb.resize((size_t)nx * ny * 3);
+    for (size_t i = 0; i < (size_t)nx * ny; i++)
+        for (int c = 0; c < 3; c++) rgb[i * 3 + c] = d[p + i * ch + (ch == 3 ? c : 0)];
+    return true;
+}
+
+// ---- BMP (BITMAPINFOHEADER, BI_RGB, 24/32 bpp) ----
+bool decode_bmp(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
+    auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, &d[o], 4); return v; };
+    auto i32 = [&](size_t o) { int32_t v; memcpy(&v, &d[o], 4); return v; };
+    auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, &d[o], 2); return v; };
+    const uint32_t off = u32(10);
+    const int w = i32(18), hh = i32(22), bpp = u16(28);
+    if (u32(30) != 0 || (bpp != 24 && bpp != 32) || w <= 0 || hh == 0) return false;
+    const int h = hh < 0 ? -hh : hh;
+    const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
+    if (d.size() < off + stride * h) return false;
+    nx = w; ny = h;
+    rgb.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) {
+        const uint8_t * row = &d[off + stride * (hh < 0 ? y : h - 1 - y)];
+        for (int x = 0; x < w; x++) {
+            const uint8_t * px = row + (size_t)x * (bpp / 8);
+            uint8_t * o = &rgb[((size_t)y * w + x) * 3];
+            o[0] = px[2]; o[1] = px[1]; o[2] = px[0];
+        }
+    }
+    return true;
+}
+
+// ---- PNG ----
+inline uint32_t be32(const uint8_t * p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+inline int paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+bool unfilter(uint8_t * data, size_t & pos, size_t avail, int w, int h, int bpp_bits, std::vector<uint8_t> & out) {
+    // data at pos: h scanlines of (1 + rowbytes); writes raw pixels rows into out (rowbytes each)
+    const size_t rowbytes = ((size_t)w * bpp_bits + 7) / 8;
+    const int bpp = std::max(1, bpp_bits / 8);
+    out.assign(rowbytes * h, 0);
+    std::vector<uint8_t> zero(rowbytes, 0);
+    for (int y = 0; y < h; y++) {
+        if (pos + 1 + rowbytes > avail) return false;
+        const int ft = data[pos];
+        const uint8_t * src = data + pos + 1;
+        uint8_t * cur = &out[rowbytes * y];
+        const uint8_t * up = y ? &out[rowbytes * (y - 1)] : zero.data();
+        for (size_t i = 0; i < rowbytes; i++) {
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up[i], c = i >= (size_t)bpp ? up[i - bpp] : 0;
+            int v = src[i];
+            switch (ft) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth(a, b, c); break;
+            default: return false;
+            }
+            cur[i] = (uint8_t)v;
+        }
+        pos += 1 + rowbytes;
+    }
+    return true;
+}
+
+bool decode_png(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) return false;
+    size_t p = 8;
+    int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    while (p + 12 <= d.size()) {
+        const uint32_t len = be32(&d[p]);
+        const uint8_t * type = &d[p + 4];
+        if (p + 12 + len > d.size()) return false;
+        const uint8_t * body = &d[p + 8];
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len < 13) return false;
+            w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        p += 12 + len;
+    }
+    if (w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15)) return false;
+    int chans;
+    switch (ctype) {
+    case 0: chans = 1; break;
+    case 2: chans = 3; break;
+    case 3: chans = 1; break;
+    case 4: chans = 2; break;
+    case 6: chans = 4; break;
+    default: return false;
+    }
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
+    const int bpp_bits = chans * depth;
+    // inflate
+    size_t raw_cap = 0;
+    if (!interlace) raw_cap = (((size_t)w * bpp_bits + 7) / 8 + 1) * h;
+    else raw_cap = (((size_t)w * bpp_bits + 7) / 8 + 8) * (h + 8) * 2;
+    std::vector<uint8_t> raw(raw_cap);
+    uLongf dl = (uLongf)raw.size();
+    if (uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size()) != Z_OK) return false;
+
+    nx = w; ny = h;
+    rgb.assign((size_t)w * h * 3, 0);
+    auto put_pixel = [&](const std::vector<uint8_t> & rows, int pw, int px, int py, int ox, int oy) {
+        // fetch pixel (px,py) of a (sub)image with width pw from unfiltered rows -> rgb[oy][ox]
+        const size_t rowbytes = ((size_t)pw * bpp_bits + 7) / 8;
+        const uint8_t * row = &rows[rowbytes * py];
+        int v[4] = {0, 0, 0, 255};
+        if (depth < 8) {
+            const int bit = px * depth;
+            const int s = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+            v[0] = ctype == 3 ? s : s * 255 / ((1 << depth) - 1);
+        } else {
+            const int bs = depth / 8;
+            for (int c = 0; c < chans; c++) v[c] = row[((size_t)px * chans + c) * bs];  // 16-bit: high byte
+        }
+        uint8_t * o = &rgb[((size_t)oy * w + ox) * 3];
+        if (ctype == 3) {
+            const size_t idx = (size_t)v[0] * 3;
+            if (idx + 2 < plte.size()) { o[0] = plte[idx]; o[1] = plte[idx + 1]; o[2] = plte[idx + 2]; }
+        } else if (ctype == 0 || ctype == 4) {
+            o[0] = o[1] = o[2] = (uint8_t)v[0];
+        } else {
+            o[0] = (uint8_t)v[0]; o[1] = (uint8_t)v[1]; o[2] = (uint8_t)v[2];
+        }
+    };
+    size_t pos = 0;
+    std::vector<uint8_t> rows;
+    if (!interlace) {
+        if (!unfilter(raw.data(), pos, dl, w, h, bpp_bits, rows)) return false;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) put_pixel(rows, w, x, y, x, y);
+    } else {
+        static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int pass = 0; pass < 7; pass++) {
+            const int pw = (w - xs[pass] + dx[pass] - 1) / dx[pass], ph = (h - ys[pass] + dy[pass] - 1) / dy[pass];
+            if (pw <= 0 || ph <= 0) continue;
+            if (!unfilter(raw.data(), pos, dl, pw, ph, bpp_bits, rows)) return false;
+            for (int y = 0; y < ph; y++)
+                for (int x = 0; x < pw; x++) put_pixel(rows, pw, x, y, xs[pass] + x * dx[pass], ys[pass] + y * dy[pass]);
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+bool load_image_file(const char * fname, clip_image_u8 * img) {
+    std::vector<uint8_t> d, rgb;
+    int nx = 0, ny = 0;
+    std::string err;
+    bool ok = read_file(fname, d);
+    if (ok) {
+        ok = decode_pnm(d, rgb, nx, ny) || decode_bmp(d, rgb, nx, ny) || decode_png(d, rgb, nx, ny) ||
+             decode_jpeg(d.data(), d.size(), rgb, nx, ny, err);
+    }
+    if (!ok) {
+        fprintf(stderr, "%s: failed to load '%s'%s%s\n", "clip_image_load_from_file", fname, err.empty() ? "" : ": ", err.c_str());
+        return false;
+    }
+    img->nx = nx;
+    img->ny = ny;
+    img->size = (size_t)nx * ny * 3;
+    img->data = new uint8_t[img->size]();
+    memcpy(img->data, rgb.data(), img->size);
+    return true;
+}
+
+}  // namespace clipamd

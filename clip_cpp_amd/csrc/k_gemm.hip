@@ -1,0 +1,390 @@
+// k_gemm.hip — fused dequant + MFMA GEMM for gfx950 (CDNA4).
+//
+//   out[M][N] = epilogue( X[M][K] (fp16) · W[N][K]^T (f16 | q4_0 | q4_1 | q5_0 | q5_1 | q8_0) + bias )
+//
+// This one kernel carries >= 96 % of the FLOPs of the hot path: the q/k/v/out projections, both FFN
+// mat-muls, the patch-embedding contraction and the final projection — i.e. every ggml_mul_mat
+// with a weight operand in reference clip.cpp:1360-1380,1392,1407,1416,1443 (vision) and
+// :1079-1095,1112,1127,1136,1160 (text), plus ggml_conv_2d at :1309.
+//
+// Design (MI355X-first, not a port of ggml's vec_dot kernels):
+//   * block-quantised weights stay quantised in HBM; each workgroup streams the [BN rows x 2 blocks]
+//     slab of its tile with one coalesced 16 B load per lane (block-column-major planes, kernels.h),
+//     dequantises in registers with packed-fp16 VALU (magic-number 0x6400|q trick, v_pk_add/v_pk_mul)
+//     and stages the fp16 tile in LDS;
+//   * activations are fp16 (the producing kernel's epilogue rounded them once), staged through LDS;
+//   * both LDS tiles are [rows][64] fp16 with a 16-byte-chunk XOR swizzle (chunk ^= row & 7) so the
+//     ds_read_b128 fragment reads of v_mfma_f32_16x16x32_f16 are bank-conflict free;
+//   * 256 threads = 4 waves in a 2x2 grid; each wave owns a (BN/2)x(BM/2) sub-tile as 16x16 MFMA
+//     fragments, fp32 accumulation; the weight is the MFMA "A" operand so that each lane ends up with
+//     4 consecutive output columns of one row -> 8/16-byte epilogue stores;
+//   * register-prefetch double buffering: tile k+1 is loaded (quantised) into VGPRs before the MFMAs of
+//     tile k are issued, dequantised + written to the other LDS buffer afterwards, one barrier per step;
+//   * workgroup -> tile mapping is XCD-aware (blocks that share a weight slab land on the same L2).
+//
+// Roofline: compute (MFMA fp16, 2.5 PFLOP/s dense) for M >= ~256; HBM (weight bytes) for M <= 64.
+
+#include "kernels.h"
+
+namespace clipamd {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 64;          // K step per iteration (two 32-wide quant blocks)
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ h2 u2h(uint32_t u) { return __builtin_bit_cast(h2, u); }
+__device__ __forceinline__ uint32_t h2u(h2 h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ h2 splat(float x) { return (h2){(_Float16)x, (_Float16)x}; }
+
+// offset (in halfs) of 16-byte chunk c (0..7) of row r in a swizzled [rows][64] fp16 LDS tile
+__device__ __forceinline__ int lds_off(int r, int c) { return r * BK + ((c ^ (r & 7)) << 3); }
+
+// ---------------------------------------------------------------------------------------------
+// Raw (still quantised) per-thread slice of the weight tile, and its dequantisation to 4 x uint4
+// (= 32 fp16 = one quant block = chunks 0..3 of that block).
+// ---------------------------------------------------------------------------------------------
+template <int WT> struct RawBlock;
+
+template <> struct RawBlock<W_Q4_0> { uint4 qs; half_t d; };
+template <> struct RawBlock<W_Q4_1> { uint4 qs; h2 dm; };
+template <> struct RawBlock<W_Q5_0> { uint4 qs; uint32_t qh; half_t d; };
+template <> struct RawBlock<W_Q5_1> { uint4 qs; uint32_t qh; h2 dm; };
+template <> struct RawBlock<W_Q8_0> { uint4 qs0, qs1; half_t d; };
+
+template <int WT>
+__device__ __forceinline__ void load_block(RawBlock<WT> & r, const DevWeight & W, size_t idx) {
+    if constexpr (WT == W_Q8_0) {
+        const uint4 * q = (const uint4 *)W.qs + idx * 2;
+        r.qs0 = q[0];
+        r.qs1 = q[1];
+    } else {
+        r.qs = ((const uint4 *)W.qs)[idx];
+    }
+    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) r.qh = ((const uint32_t *)W.qh)[idx];
+    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) r.dm = ((const h2 *)W.dm)[idx];
+    else r.d = ((const half_t *)W.dm)[idx];
+}
+
+// Packed nibble layout (model.cpp repack_q4/q5): 32-bit word j of qs holds elements 8j..8j+7 of the
+// block; nibble p<4 is element 2p, nibble p>=4 is element 2(p-4)+1.  Hence
+//   ((w >> 4s) & 0x000F000F) = { lo half: element 2s, hi half: element 2s+1 }  (adjacent pair).
+// OR-ing 0x6400 into each half gives the fp16 number 1024+q exactly.
+template <int WT>
+__device__ __forceinline__ void dequant_block(const RawBlock<WT> & r, uint4 (&out)[4]) {
+    if constexpr (WT == W_Q4_0 || WT == W_Q4_1 || WT == W_Q5_0 || WT == W_Q5_1) {
+        const uint32_t w[4] = {r.qs.x, r.qs.y, r.qs.z, r.qs.w};
+        h2 scale, sub, add;
+        if constexpr (WT == W_Q4_0) { scale = (h2){r.d, r.d}; sub = splat(1032.0f); }
+        if constexpr (WT == W_Q5_0) { scale = (h2){r.d, r.d}; sub = splat(1040.0f); }
+        if constexpr (WT == W_Q4_1 || WT == W_Q5_1) {
+            scale = (h2){r.dm[0], r.dm[0]};
+            add = (h2){r.dm[1], r.dm[1]};
+            sub = splat(1024.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t o[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                uint32_t u = ((w[j] >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
+                if constexpr (WT == W_Q5_0 || WT == W_Q5_1) {
+                    // fifth bits: pair index pi = 4j+s; bit pi -> element 2s, bit 16+pi -> element 2s+1
+                    constexpr uint32_t M5 = 0x00100010u;
+                    const int pi = 4 * j + s;
+                    const uint32_t hb = (pi >= 4) ? (r.qh >> (pi - 4)) : (r.qh << (4 - pi));
+                    u |= hb & M5;
+                }
+                h2 v = u2h(u) - sub;  // exact small integer
+                if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = v * scale + add;
+                else v = v * scale;
+                o[s] = h2u(v);
+            }
+            out[j] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    } else if constexpr (WT == W_Q8_0) {
+        // bytes are stored as (int8 ^ 0x80) in the order [e0, e2, e1, e3] per 32-bit word, so
+        //   (w & 0x00FF00FF) = {e0, e1},  ((w >> 8) & 0x00FF00FF) = {e2, e3}; 0x6400|u8 = 1024 + (q+128).
+        const uint32_t w[8] = {r.qs0.x, r.qs0.y, r.qs0.z, r.qs0.w, r.qs1.x, r.qs1.y, r.qs1.z, r.qs1.w};
+        const h2 scale = (h2){r.d, r.d};
+        const h2 sub = splat(1152.0f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t o[4];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint32_t ww = w[2 * j + t];
+                const uint32_t u0 = (ww & 0x00FF00FFu) | 0x64006400u;
+                const uint32_t u1 = ((ww >> 8) & 0x00FF00FFu) | 0x64006400u;
+                o[2 * t + 0] = h2u((u2h(u0) - sub) * scale);
+                o[2 * t + 1] = h2u((u2h(u1) - sub) * scale);
+            }
+            out[j] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // ggml_gelu_f32: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))
+    const float u = 0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1)
+    const float e = __expf(2.0f * u);
+    const float th = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + th);
+}
+__device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+// ---------------------------------------------------------------------------------------------
+template <int WT, int BM, int BN, int EPI>
+__global__ void __launch_bounds__(NTHREADS) gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t * Ws = (half_t *)smem_raw;                 // [2][BN*BK]
+    half_t * Xs = Ws + 2 * BN * BK;                   // [2][BM*BK]
+
+    constexpr int TN = BN / 32;   // 16-row MFMA fragments per wave along N (wave owns BN/2 rows)
+    constexpr int TM = BM / 32;
+    constexpr int XCH = BM * 8 / NTHREADS;            // 16 B chunks of the X tile per thread
+    constexpr int WCH = BN * 8 / NTHREADS;            // (f16 weights) chunks per thread
+    constexpr int WBLK = (BN * 2 + NTHREADS - 1) / NTHREADS;  // (quant) blocks per thread
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    // ---- XCD-aware tile mapping (bijective for any grid size) ----
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.W.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nk = p.W.Kpad / BK;
+    const int nkb = p.W.Kpad / 32;
+    (void)nkb;
+
+    // ---- per-thread global source coordinates ----
+    const half_t * xsrc[XCH];
+    int xdst[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; i++) {
+        const int q = tid + i * NTHREADS;
+        const int row = q >> 3, c = q & 7;
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;  // clamp: rows past M are computed but never stored
+        xsrc[i] = p.A + (size_t)gm * p.lda + c * 8;
+        xdst[i] = lds_off(row, c);
+    }
+
+    uint4 xr[XCH];
+    uint4 wr16[WT == W_F16 ? WCH : 1];
+    RawBlock<(WT == W_F16 ? W_Q4_0 : WT)> wrq[WT == W_F16 ? 1 : WBLK];
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < XCH; i++) xr[i] = *(const uint4 *)(xsrc[i] + kt * BK);
+        if constexpr (WT == W_F16) {
+#pragma unroll
+            for (int i = 0; i < WCH; i++) {
+                const int q = tid + i * NTHREADS;
+                const int row = q >> 3, c = q & 7;
+                wr16[i] = *(const uint4 *)((const half_t *)p.W.w16 + (size_t)(n0 + row) * p.W.Kpad + kt * BK + c * 8);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WBLK; i++) {
+                const int item = tid + i * NTHREADS;
+                if (item < BN * 2) {
+                    const int nl = item % BN, kbl = item / BN;
+                    load_block<WT>(wrq[i], p.W, (size_t)(kt * 2 + kbl) * p.W.Npad + n0 + nl);
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        half_t * xs = Xs + buf * BM * BK;
+        half_t * ws = Ws + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < XCH; i++) *(uint4 *)(xs + xdst[i]) = xr[i];
+        if constexpr (WT == W_F16) {
+#pragma unroll
+            for (int i = 0; i < WCH; i++) {
+                const int q = tid + i * NTHREADS;
+                *(uint4 *)(ws + lds_off(q >> 3, q & 7)) = wr16[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WBLK; i++) {
+                const int item = tid + i * NTHREADS;
+                if (item < BN * 2) {
+                    const int nl = item % BN, kbl = item / BN;
+                    uint4 dq[4];
+                    dequant_block<WT>(wrq[i], dq);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) *(uint4 *)(ws + lds_off(nl, kbl * 4 + j)) = dq[j];
+                }
+            }
+        }
+    };
+
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const half_t * xs = Xs + cur * BM * BK;
+        const half_t * ws = Ws + cur * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            h8 wf[TN], xf[TM];
+#pragma unroll
+            for (int a = 0; a < TN; a++) {
+                const int row = wn * (BN / 2) + a * 16 + frow;
+                wf[a] = *(const h8 *)(ws + lds_off(row, kk * 4 + fgrp));
+            }
+#pragma unroll
+            for (int b = 0; b < TM; b++) {
+                const int row = wm * (BM / 2) + b * 16 + frow;
+                xf[b] = *(const h8 *)(xs + lds_off(row, kk * 4 + fgrp));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15)
+    const int N = p.W.N;
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        const int n = n0 + wn * (BN / 2) + a * 16 + fgrp * 4;
+        if (n >= N) continue;
+        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_PATCH_F32 && p.bias) bias = *(const f4 *)(p.bias + n);
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            const int m = m0 + wm * (BM / 2) + b * 16 + frow;
+            if (m >= p.M) continue;
+            f4 v = acc[a][b] + bias;
+            if constexpr (EPI == EPI_F32) {
+                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                const f4 r = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
+                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r + v;
+            } else if constexpr (EPI == EPI_PATCH_F32) {
+                const int img = m / p.Np, pp = m % p.Np;
+                const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
+                *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
+            } else {
+                if constexpr (EPI == EPI_F16) {
+                    if (n < p.qcols) v = v * p.qscale;
+                } else if constexpr (EPI == EPI_GELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
+                } else if constexpr (EPI == EPI_QGELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
+                }
+                const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
+                const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
+                *(uint2 *)((half_t *)p.out + (size_t)m * p.ldc + n) = make_uint2(h2u(lo), h2u(hi));
+            }
+        }
+    }
+}
+
+template <int WT, int BM, int BN, int EPI>
+void launch_one(const GemmParams & p, hipStream_t stream) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
+    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
+}
+
+template <int WT, int EPI>
+void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
+    switch (tile) {
+    case 128128: launch_one<WT, 128, 128, EPI>(p, stream); break;
+    case 64128: launch_one<WT, 64, 128, EPI>(p, stream); break;
+    case 128064: launch_one<WT, 128, 64, EPI>(p, stream); break;
+    default: launch_one<WT, 64, 64, EPI>(p, stream); break;
+    }
+}
+
+template <int WT>
+void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
+    switch (epi) {
+    case EPI_F32: launch_tile<WT, EPI_F32>(p, tile, stream); break;
+    case EPI_F16: launch_tile<WT, EPI_F16>(p, tile, stream); break;
+    case EPI_GELU_F16: launch_tile<WT, EPI_GELU_F16>(p, tile, stream); break;
+    case EPI_QGELU_F16: launch_tile<WT, EPI_QGELU_F16>(p, tile, stream); break;
+    case EPI_RESID_F32: launch_tile<WT, EPI_RESID_F32>(p, tile, stream); break;
+    case EPI_PATCH_F32: launch_tile<WT, EPI_PATCH_F32>(p, tile, stream); break;
+    }
+}
+
+// Tile heuristic: biggest tile that still yields >= ~1 workgroup per CU (256 CUs).
+int pick_tile(int M, int N) {
+    auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (M <= 64) return N >= 2048 ? 64128 : 64064;
+    if (wgs(128, 128) >= 384) return 128128;
+    if (wgs(64, 128) >= 256) return 64128;
+    if (wgs(128, 128) >= 200) return 128128;
+    return 64064;
+}
+
+}  // namespace
+
+// One translation unit per weight type (compiled in parallel by build.py with -DCLIPAMD_GEMM_WT=<n>);
+// the dispatcher is compiled once with no define.
+#ifdef CLIPAMD_GEMM_WT
+#define CLIPAMD_CAT2(a, b) a##b
+#define CLIPAMD_CAT(a, b) CLIPAMD_CAT2(a, b)
+void CLIPAMD_CAT(launch_gemm_wt, CLIPAMD_GEMM_WT)(const GemmParams & p, int epilogue, int tile, hipStream_t stream) {
+    launch_epi<CLIPAMD_GEMM_WT>(p, epilogue, tile, stream);
+}
+#else
+void launch_gemm_wt0(const GemmParams &, int, int, hipStream_t);
+void launch_gemm_wt1(const GemmParams &, int, int, hipStream_t);
+void launch_gemm_wt2(const GemmParams &, int, int, hipStream_t);
+void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
+void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
+void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
+
+void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream) {
+    if (p.M <= 0) return;
+    if (tile == 0) tile = pick_tile(p.M, p.W.N);
+    switch (p.W.wtype) {
+    case W_F16: launch_gemm_wt0(p, epilogue, tile, stream); break;
+    case W_Q4_0: launch_gemm_wt1(p, epilogue, tile, stream); break;
+    case W_Q4_1: launch_gemm_wt2(p, epilogue, tile, stream); break;
+    case W_Q5_0: launch_gemm_wt3(p, epilogue, tile, stream); break;
+    case W_Q5_1: launch_gemm_wt4(p, epilogue, tile, stream); break;
+    case W_Q8_0: launch_gemm_wt5(p, epilogue, tile, stream); break;
+    }
+}
+#endif
+
+}  // namespace clipamd

@@ -1,0 +1,268 @@
+// k_misc.hip — the memory-bound kernels of the hot path (HBM roofline): LayerNorm, im2col for the
+// patch convolution, class-token rows, text embedding gather, L2 normalisation, dtype conversion.
+// Each replaces a chain of materialised ggml temporaries (repeat/mul/add/acc/get_rows/cont,
+// SURVEY §8a "where the CPU time goes") with ONE pass over the data.
+
+#include "kernels.h"
+
+namespace clipamd {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one 64-lane wave per row, row held in registers (h <= 64*4*MAXV), two-pass mean/variance
+// (ggml_norm semantics: biased variance, y = (x-mean) * 1/sqrt(var+eps), then *w + b;
+// reference clip.cpp:1350-1355, ggml_compute_forward_norm).  Wave-shuffle reductions only.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // float4 per lane -> h <= 2048
+
+__global__ void __launch_bounds__(256) layernorm_kernel(const float * __restrict__ x, int ldx, const int * __restrict__ in_rows, int in_row_mul,
+                                                        const float * __restrict__ w, const float * __restrict__ b, float eps,
+                                                        int rows, int h, half_t * __restrict__ out16, int ld16,
+                                                        float * __restrict__ out32, int ld32) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long src = in_rows ? (long)in_rows[r] : (long)r * in_row_mul;
+    const float * xr = x + (size_t)src * ldx;
+    f4 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < h) {
+            v[i] = *(const f4 *)(xr + c);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)h;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < h) {
+            v[i] = v[i] - mean;
+            sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    const float var = wave_sum(sq) / (float)h;
+    const float scale = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < h) {
+            const f4 ww = *(const f4 *)(w + c), bb = *(const f4 *)(b + c);
+            const f4 y = (v[i] * scale) * ww + bb;
+            if (out32) *(f4 *)(out32 + (size_t)r * ld32 + c) = y;
+            if (out16) {
+                const h2 lo = (h2){(_Float16)y[0], (_Float16)y[1]}, hi = (h2){(_Float16)y[2], (_Float16)y[3]};
+                *(uint2 *)(out16 + (size_t)r * ld16 + c) =
+                    make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col (fp16) for the stride-P, no-padding patch convolution: col[(b,oy,ox)][(c,ky,kx)] =
+// fp16(img[b][oy*P+ky][ox*P+kx][c]); two k's per thread, padded columns are zero.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) im2col_kernel(const float * __restrict__ imgs, half_t * __restrict__ col, int B, int S,
+                                                     int P, int Kpad, long total2) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total2) return;
+    const int kp2 = Kpad >> 1;
+    const long m = i / kp2;
+    const int k0 = (int)(i % kp2) * 2;
+    const int G = S / P, Np = G * G, K = 3 * P * P;
+    const int b = (int)(m / Np), pp = (int)(m % Np);
+    const int oy = pp / G, ox = pp % G;
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int k = k0 + e;
+        float val = 0.f;
+        if (k < K) {
+            const int c = k / (P * P), rem = k % (P * P);
+            const int ky = rem / P, kx = rem % P;
+            val = imgs[(size_t)b * S * S * 3 + 3 * ((size_t)(oy * P + ky) * S + (ox * P + kx)) + c];
+        }
+        v[e] = val;
+    }
+    const h2 o = (h2){(_Float16)v[0], (_Float16)v[1]};
+    *(uint32_t *)(col + (size_t)m * Kpad + k0) = __builtin_bit_cast(uint32_t, o);
+}
+
+__global__ void __launch_bounds__(256) cls_rows_kernel(float * __restrict__ x, const float * __restrict__ cls,
+                                                       const float * __restrict__ pos, int B, int T, int h) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * h) return;
+    const int b = i / h, c = i % h;
+    x[(size_t)b * T * h + c] = cls[c] + pos[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Text embedding: x[row] = dequantize_row(token_embd[id]) + pos[t]   (ggml_get_rows dequantises the
+// embedding tables exactly; reference clip.cpp:1059-1061).  Raw ggml block layouts are read byte-wise
+// (18/20/22/24/34-byte blocks are only 2-byte aligned).  One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld_h(const uint8_t * p) {
+    const uint16_t u = (uint16_t)p[0] | ((uint16_t)p[1] << 8);
+    return (float)__builtin_bit_cast(_Float16, u);
+}
+
+__device__ float dequant_elem(const uint8_t * row, int type, int k) {
+    const int ib = k >> 5, j = k & 31;
+    switch (type) {
+    case 0: return ((const float *)row)[k];
+    case 1: return ld_h(row + 2 * k);
+    case 2: {  // q4_0
+        const uint8_t * blk = row + ib * 18;
+        const uint8_t q = blk[2 + (j & 15)];
+        return (float)((j < 16 ? (q & 0x0F) : (q >> 4)) - 8) * ld_h(blk);
+    }
+    case 3: {  // q4_1
+        const uint8_t * blk = row + ib * 20;
+        const uint8_t q = blk[4 + (j & 15)];
+        return (float)(j < 16 ? (q & 0x0F) : (q >> 4)) * ld_h(blk) + ld_h(blk + 2);
+    }
+    case 6: {  // q5_0
+        const uint8_t * blk = row + ib * 22;
+        const uint32_t qh = blk[2] | (blk[3] << 8) | (blk[4] << 16) | ((uint32_t)blk[5] << 24);
+        const uint8_t q = blk[6 + (j & 15)];
+        const int lo = j < 16 ? (q & 0x0F) : (q >> 4);
+        const int hi = (qh >> j) & 1;
+        return (float)((lo | (hi << 4)) - 16) * ld_h(blk);
+    }
+    case 7: {  // q5_1
+        const uint8_t * blk = row + ib * 24;
+        const uint32_t qh = blk[4] | (blk[5] << 8) | (blk[6] << 16) | ((uint32_t)blk[7] << 24);
+        const uint8_t q = blk[8 + (j & 15)];
+        const int lo = j < 16 ? (q & 0x0F) : (q >> 4);
+        const int hi = (qh >> j) & 1;
+        return (float)(lo | (hi << 4)) * ld_h(blk) + ld_h(blk + 2);
+    }
+    case 8: {  // q8_0
+        const uint8_t * blk = row + ib * 34;
+        return (float)(int8_t)blk[2 + j] * ld_h(blk);
+    }
+    }
+    return 0.f;
+}
+
+__global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restrict__ ids, const int * __restrict__ seq_start, int nseq,
+                                                         const uint8_t * __restrict__ tok, int tok_type, size_t tok_row_bytes,
+                                                         const float * __restrict__ pos, int h, float * __restrict__ x) {
+    const int row = blockIdx.x;
+    // position within its sequence: binary search seq_start (nseq+1 entries, ascending)
+    int lo = 0, hi = nseq;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seq_start[mid] <= row) lo = mid; else hi = mid;
+    }
+    const int t = row - seq_start[lo];
+    const uint8_t * trow = tok + (size_t)ids[row] * tok_row_bytes;
+    for (int c = threadIdx.x; c < h; c += 256)
+        x[(size_t)row * h + c] = pos[(size_t)t * h + c] + dequant_elem(trow, tok_type, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) l2norm_kernel(const float * __restrict__ v, float * __restrict__ out, int rows, int n,
+                                                     int normalize) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float * vr = v + (size_t)r * n;
+    float sq = 0.f;
+    for (int c = lane; c < n; c += 64) sq += vr[c] * vr[c];
+    sq = wave_sum(sq);
+    const float inv = normalize ? 1.0f / sqrtf(sq) : 1.0f;
+    for (int c = lane; c < n; c += 64) out[(size_t)r * n + c] = vr[c] * inv;
+}
+
+__global__ void __launch_bounds__(256) f32_to_f16_kernel(const float * __restrict__ src, int lds, half_t * __restrict__ dst, int ldd,
+                                                         int rows, int cols, int cols_pad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols_pad) return;
+    const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+    dst[(size_t)r * ldd + c] = c < cols ? (_Float16)src[(size_t)r * lds + c] : (_Float16)0.f;
+}
+__global__ void __launch_bounds__(256) f16_to_f32_kernel(const half_t * __restrict__ src, int lds, float * __restrict__ dst, int ldd,
+                                                         int rows, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(size_t)r * ldd + c] = (float)src[(size_t)r * lds + c];
+}
+
+}  // namespace
+
+void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_mul, const float * w, const float * b, float eps,
+                      int rows, int h, half_t * out16, int ld16, float * out32, int ld32, hipStream_t stream) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, in_rows, in_row_mul, w, b, eps, rows, h,
+                       out16, ld16, out32, ld32);
+}
+
+void launch_im2col(const float * imgs, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream) {
+    const int G = S / P;
+    const long total2 = (long)B * G * G * (Kpad / 2);
+    if (total2 <= 0) return;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, imgs, col, B, S, P, Kpad,
+                       total2);
+}
+
+void launch_cls_rows(float * x, const float * class_embd, const float * pos, int B, int T, int h, hipStream_t stream) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * h + 255) / 256), dim3(256), 0, stream, x, class_embd, pos, B, T, h);
+}
+
+static size_t raw_row_bytes(int type, int k) {
+    switch (type) {
+    case 0: return (size_t)k * 4;
+    case 1: return (size_t)k * 2;
+    case 2: return (size_t)(k / 32) * 18;
+    case 3: return (size_t)(k / 32) * 20;
+    case 6: return (size_t)(k / 32) * 22;
+    case 7: return (size_t)(k / 32) * 24;
+    case 8: return (size_t)(k / 32) * 34;
+    }
+    return 0;
+}
+
+void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw, int tok_type,
+                       const float * pos, int h, float * x, hipStream_t stream) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(text_embed_kernel, dim3(rows), dim3(256), 0, stream, ids, seq_start, nseq, (const uint8_t *)tok_raw,
+                       tok_type, raw_row_bytes(tok_type, h), pos, h, x);
+}
+
+void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, v, out, rows, n, normalize ? 1 : 0);
+}
+
+void launch_f32_to_f16(const float * src, int lds, half_t * dst, int ldd, int rows, int cols, int cols_pad,
+                       hipStream_t stream) {
+    const long total = (long)rows * cols_pad;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows,
+                       cols, cols_pad);
+}
+void launch_f16_to_f32(const half_t * src, int lds, float * dst, int ldd, int rows, int cols, hipStream_t stream) {
+    const long total = (long)rows * cols;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows,
+                       cols);
+}
+
+}  // namespace clipamd

@@ -1,0 +1,95 @@
+// kernels.h — launch interface of the gfx950 HIP kernels (device side of the hot path).
+//
+// Hot path = reference clip.cpp:1247-1523 (vision) and :1016-1233 (text); the ggml ops those
+// graph builders invoke are replaced by the kernels declared here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace clipamd {
+
+typedef _Float16 half_t;
+
+// Device weight formats (repacked from the ggml block layout at load time, see model.cpp).
+enum WType : int { W_F16 = 0, W_Q4_0 = 1, W_Q4_1 = 2, W_Q5_0 = 3, W_Q5_1 = 4, W_Q8_0 = 5 };
+
+// One linear weight W[N][K] (y = W x), resident in HBM in the GEMM-friendly layout:
+//   W_F16 : w16[Npad][Kpad] row-major fp16 (zero padded)
+//   quant : "block-column-major" planes over nkb = Kpad/32 blocks of 32 weights:
+//           qs[kb][n]  16 B (q8_0: 32 B) of packed quants, nibble/byte order permuted for cheap unpack
+//           qh[kb][n]  4 B of fifth bits (q5_*), permuted
+//           dm[kb][n]  fp16 scale d (q4_0,q5_0,q8_0) or half2 {d, m} (q4_1,q5_1)
+//   so that the 128 rows of a tile at one kb are contiguous (coalesced 16 B/lane loads).
+struct DevWeight {
+    int wtype = W_F16;
+    int N = 0, K = 0;      // logical shape
+    int Npad = 0;          // multiple of 128 (padded rows are zero)
+    int Kpad = 0;          // multiple of 64  (padded blocks are zero)
+    const void * qs = nullptr;
+    const void * qh = nullptr;
+    const void * dm = nullptr;
+    const void * w16 = nullptr;
+};
+
+enum Epilogue : int {
+    EPI_F32 = 0,        // out f32 = acc (+bias)
+    EPI_F16 = 1,        // out f16 = (acc + bias) * (n < qcols ? qscale : 1)
+    EPI_GELU_F16 = 2,   // out f16 = gelu_tanh(acc + bias)
+    EPI_QGELU_F16 = 3,  // out f16 = quick_gelu(acc + bias)
+    EPI_RESID_F32 = 4,  // out f32 = resid + acc + bias      (resid may alias out)
+    EPI_PATCH_F32 = 5,  // out f32 row (m/Np)*T+1+m%Np = acc + pos[1+m%Np]   (patch embedding)
+    EPI_COUNT = 6
+};
+
+struct GemmParams {
+    const half_t * A = nullptr;  // activations [M][lda] fp16, lda >= Kpad
+    int lda = 0;
+    int M = 0;
+    DevWeight W;
+    const float * bias = nullptr;
+    void * out = nullptr;
+    int ldc = 0;
+    const float * resid = nullptr;
+    float qscale = 1.0f;
+    int qcols = 0;
+    int Np = 0, T = 0;
+    const float * pos = nullptr;
+};
+
+// tile: 0 = heuristic, else BM*1000 + BN with BM,BN in {64,128}
+void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
+
+// LayerNorm over rows of h floats (ggml_norm + mul + add, reference clip.cpp:1350-1355).
+// Row r reads x[in_rows[r]] when in_rows != nullptr, else x[r * in_row_mul] (strided gather, e.g. the
+// CLS rows b*T); out16/out32 may be null.
+void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_mul, const float * w, const float * b, float eps,
+                      int rows, int h, half_t * out16, int ld16, float * out32, int ld32, hipStream_t stream);
+
+// Multi-head self-attention softmax(QK^T)V (reference clip.cpp:1382-1388; causal for text :1101).
+// qkv: [rows][3h] fp16 with Q pre-scaled; sequences given by seq_start[nseq+1] (device) or, when
+// seq_start == nullptr, uniform length T.  out: [rows][h] fp16.
+bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform, const int * seq_start, int max_len,
+                      int h, int n_head, bool causal, hipStream_t stream);
+
+// im2col for the stride-P patch convolution (reference clip.cpp:1309; ggml conv_2d im2col, fp16):
+// imgs [B][S][S][3] f32 interleaved -> col [B*Np][Kpad] fp16, k = (c*P + ky)*P + kx, zero padded to Kpad.
+void launch_im2col(const float * imgs, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream);
+
+// x[b*T + 0][:] = class_embd + pos[0]   (reference clip.cpp:1315-1331, class-token row)
+void launch_cls_rows(float * x, const float * class_embd, const float * pos, int B, int T, int h, hipStream_t stream);
+
+// text embedding: x[r][:] = dequant(token_embd[ids[r]]) + pos[r - seq_start(r)]  (reference clip.cpp:1059-1061)
+// tok_raw is the token_embd tensor in its ggml block layout (type = ggml type id).
+void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw,
+                       int tok_type, const float * pos, int h, float * x, hipStream_t stream);
+
+// out[r][:] = v[r][:] / ||v[r]||_2  (reference clip.cpp:1446-1455) or plain copy when !normalize
+void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream);
+
+// fp32 -> fp16 conversion of a [rows][cols] matrix into a padded fp16 matrix (test hooks / inputs)
+void launch_f32_to_f16(const float * src, int lds, half_t * dst, int ldd, int rows, int cols, int cols_pad,
+                       hipStream_t stream);
+void launch_f16_to_f32(const half_t * src, int lds, float * dst, int ldd, int rows, int cols, hipStream_t stream);
+
+}  // namespace clipamd

@@ -1,0 +1,432 @@
+// load.cpp — clip_model_load for the MI355X build: GGUF -> host staging -> ONE HBM allocation.
+//
+// Reference behaviour being replaced: clip.cpp:334-596 (parse KV, read every tensor into a ggml
+// arena, bind by name).  Here every linear weight is repacked ONCE into the block-column-major planes
+// the GEMM kernel streams (kernels.h / k_gemm.hip), q/k/v are fused into a single [3h][h] weight,
+// position embeddings are dequantised to f32 (what ggml_get_rows would do on every call), everything
+// is laid out in a single host buffer and uploaded with one hipMemcpy.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "model.h"
+
+namespace clipamd {
+
+namespace {
+
+// ---- repack of one ggml-layout weight tensor into the GEMM planes (layout: kernels.h, k_gemm.hip) ----
+struct RepackPlan {
+    DevWeight W;
+    size_t bytes_qs = 0, bytes_qh = 0, bytes_dm = 0, bytes_w16 = 0;
+    int blk_bytes = 0, o_m = -1, o_qh = -1, o_qs = 2;
+    bool is8 = false;
+};
+
+bool plan_repack(int type, int64_t N, int64_t K, RepackPlan & pl, std::string & err) {
+    DevWeight & W = pl.W;
+    W.N = (int)N;
+    W.K = (int)K;
+    W.Npad = (int)((N + 127) / 128 * 128);
+    W.Kpad = (int)((K + 63) / 64 * 64);
+    if (type == GT_F32 || type == GT_F16) {
+        // f32 linear weights are rounded to fp16 once here (the MFMA path has fp16 operands)
+        W.wtype = W_F16;
+        pl.bytes_w16 = (size_t)W.Npad * W.Kpad * 2;
+        return true;
+    }
+    if (K % 32) { err = "quantised tensor with K % 32 != 0"; return false; }
+    switch (type) {
+    case GT_Q4_0: W.wtype = W_Q4_0; pl.blk_bytes = 18; break;
+    case GT_Q4_1: W.wtype = W_Q4_1; pl.blk_bytes = 20; pl.o_m = 2; pl.o_qs = 4; break;
+    case GT_Q5_0: W.wtype = W_Q5_0; pl.blk_bytes = 22; pl.o_qh = 2; pl.o_qs = 6; break;
+    case GT_Q5_1: W.wtype = W_Q5_1; pl.blk_bytes = 24; pl.o_m = 2; pl.o_qh = 4; pl.o_qs = 8; break;
+    case GT_Q8_0: W.wtype = W_Q8_0; pl.blk_bytes = 34; pl.is8 = true; break;
+    default: err = "unsupported weight type " + std::to_string(type); return false;
+    }
+    const size_t nblk = (size_t)(W.Kpad / 32) * W.Npad;
+    pl.bytes_qs = nblk * (pl.is8 ? 32 : 16);
+    pl.bytes_qh = pl.o_qh >= 0 ? nblk * 4 : 0;
+    pl.bytes_dm = nblk * (pl.o_m >= 0 ? 4 : 2);
+    return true;
+}
+
+// src: N_each rows of K weights in ggml layout; destination planes are zero-initialised by the caller.
+void repack_rows(const RepackPlan & pl, int type, const uint8_t * src, int64_t N_each, int64_t K, int64_t row_off, uint8_t * qs_out,
+                 uint8_t * qh_out, uint8_t * dm_out, uint8_t * w16_out) {
+    const DevWeight & W = pl.W;
+    if (W.wtype == W_F16) {
+        uint16_t * dst = (uint16_t *)w16_out;
+        for (int64_t n = 0; n < N_each; n++) {
+            uint16_t * drow = dst + (row_off + n) * W.Kpad;
+            if (type == GT_F16) {
+                memcpy(drow, src + (size_t)n * K * 2, (size_t)K * 2);
+            } else {
+                const float * s = (const float *)src + n * K;
+                for (int64_t k = 0; k < K; k++) drow[k] = f32_to_f16_bits(s[k]);
+            }
+        }
+        return;
+    }
+    const int64_t nb_src = K / 32;
+    const size_t rb = (size_t)nb_src * pl.blk_bytes;
+    for (int64_t n = 0; n < N_each; n++) {
+        const int64_t ng = row_off + n;
+        for (int64_t kb = 0; kb < nb_src; kb++) {
+            const uint8_t * blk = src + n * rb + kb * pl.blk_bytes;
+            const size_t idx = (size_t)kb * W.Npad + ng;
+            if (pl.o_m >= 0) {
+                memcpy(dm_out + idx * 4, blk, 2);
+                memcpy(dm_out + idx * 4 + 2, blk + pl.o_m, 2);
+            } else {
+                memcpy(dm_out + idx * 2, blk, 2);
+            }
+            if (pl.is8) {
+                // word t holds elements 4t..4t+3 as bytes [e0,e2,e1,e3], each XOR 0x80 (k_gemm.hip dequant_block)
+                uint8_t * o = qs_out + idx * 32;
+                const uint8_t * q = blk + 2;
+                for (int t = 0; t < 8; t++) {
+                    o[4 * t + 0] = q[4 * t + 0] ^ 0x80;
+                    o[4 * t + 1] = q[4 * t + 2] ^ 0x80;
+                    o[4 * t + 2] = q[4 * t + 1] ^ 0x80;
+                    o[4 * t + 3] = q[4 * t + 3] ^ 0x80;
+                }
+                continue;
+            }
+            const uint8_t * qs = blk + pl.o_qs;
+            uint32_t qh = 0;
+            if (pl.o_qh >= 0) memcpy(&qh, blk + pl.o_qh, 4);
+            uint32_t words[4] = {0, 0, 0, 0}, qh2 = 0;
+            for (int e = 0; e < 32; e++) {
+                const uint32_t nib = e < 16 ? (qs[e] & 0x0Fu) : (qs[e - 16] >> 4);
+                const int j = e >> 3, w = e & 7;                    // word j, element w within the word
+                const int p = (w & 1) ? 4 + (w >> 1) : (w >> 1);    // nibble position: pairs (2s,2s+1) -> nibbles (s, s+4)
+                words[j] |= nib << (4 * p);
+                if (pl.o_qh >= 0) {
+                    const uint32_t bit = (qh >> e) & 1u;
+                    const int pi = 4 * j + (w >> 1);                // pair index
+                    qh2 |= bit << ((w & 1) ? 16 + pi : pi);
+                }
+            }
+            memcpy(qs_out + idx * 16, words, 16);
+            if (pl.o_qh >= 0) memcpy(qh_out + idx * 4, &qh2, 4);
+        }
+    }
+}
+
+struct Stage {                       // host image of the device weight allocation
+    std::vector<uint8_t> buf;
+    size_t alloc(size_t bytes) {     // 256-byte aligned bump allocation (zero filled)
+        size_t off = (buf.size() + 255) & ~(size_t)255;
+        buf.resize(off + bytes, 0);
+        return off;
+    }
+};
+
+struct Fix {                         // pointer fix-ups applied after the upload
+    const void ** slot;
+    size_t off;
+};
+
+struct Loader {
+    const GgufFile & g;
+    Stage st;
+    std::vector<Fix> fixes;
+    std::string err;
+    explicit Loader(const GgufFile & gg) : g(gg) {}
+
+    const GgufTensorInfo * need(const std::string & name) {
+        const GgufTensorInfo * t = g.tensor(name);
+        if (!t && err.empty()) err = "unable to find tensor " + name;
+        return t;
+    }
+    void fix(const void ** slot, size_t off) { fixes.push_back({slot, off}); }
+
+    // 1-D f32 tensor (bias / LN / class_embd), optionally several concatenated
+    bool vec_f32(const std::vector<std::string> & names, const float ** slot, int64_t expect_each) {
+        std::vector<const GgufTensorInfo *> ts;
+        for (auto & n : names) {
+            const GgufTensorInfo * t = need(n);
+            if (!t) return false;
+            if (t->type != GT_F32 || t->ne[0] != expect_each || t->nrows() != 1) { err = "tensor " + n + ": expected f32[" + std::to_string(expect_each) + "]"; return false; }
+            ts.push_back(t);
+        }
+        size_t off = st.alloc((size_t)expect_each * 4 * ts.size());
+        for (size_t i = 0; i < ts.size(); i++) memcpy(&st.buf[off + i * expect_each * 4], ts[i]->data, (size_t)expect_each * 4);
+        fix((const void **)slot, off);
+        return true;
+    }
+
+    // 2-D embedding table dequantised to f32 [rows][k]
+    bool table_f32(const std::string & name, const float ** slot, int64_t k, int64_t rows) {
+        const GgufTensorInfo * t = need(name);
+        if (!t) return false;
+        if (t->ne[0] != k || t->nrows() != rows) { err = "tensor " + name + ": unexpected shape"; return false; }
+        size_t off = st.alloc((size_t)rows * k * 4);
+        const size_t rb = ggml_row_bytes(t->type, k);
+        for (int64_t r = 0; r < rows; r++) dequantize_row(t->type, t->data + r * rb, (float *)&st.buf[off] + r * k, k);
+        fix((const void **)slot, off);
+        return true;
+    }
+
+    bool raw(const std::string & name, const void ** slot, int * type, int64_t k, int64_t rows) {
+        const GgufTensorInfo * t = need(name);
+        if (!t) return false;
+        if (t->ne[0] != k || t->nrows() != rows) { err = "tensor " + name + ": unexpected shape"; return false; }
+        size_t off = st.alloc(t->nbytes);
+        memcpy(&st.buf[off], t->data, t->nbytes);
+        *type = t->type;
+        fix(slot, off);
+        return true;
+    }
+
+    // Linear weight(s) [N_i][K] concatenated along N and repacked for the GEMM kernel.
+    bool linear(const std::vector<std::string> & names, DevWeight & W, int64_t K, int64_t N_each, bool as_conv = false) {
+        std::vector<const uint8_t *> srcs;
+        int type = -1;
+        for (auto & n : names) {
+            const GgufTensorInfo * t = need(n);
+            if (!t) return false;
+            const int64_t tk = as_conv ? t->ne[0] * t->ne[1] * t->ne[2] : t->ne[0];
+            const int64_t tn = as_conv ? t->ne[3] : t->nrows();
+            if (tk != K || tn != N_each) { err = "tensor " + n + ": unexpected shape"; return false; }
+            if (type >= 0 && t->type != type) { err = "tensor " + n + ": mixed weight types in one fused projection"; return false; }
+            type = t->type;
+            srcs.push_back(t->data);
+        }
+        RepackPlan plan;
+        if (!plan_repack(type, N_each * (int64_t)srcs.size(), K, plan, err)) return false;
+        W = plan.W;
+        size_t off_qs = 0, off_qh = 0, off_dm = 0, off_w16 = 0;
+        if (plan.bytes_w16) off_w16 = st.alloc(plan.bytes_w16);
+        if (plan.bytes_qs) off_qs = st.alloc(plan.bytes_qs);
+        if (plan.bytes_qh) off_qh = st.alloc(plan.bytes_qh);
+        if (plan.bytes_dm) off_dm = st.alloc(plan.bytes_dm);
+        for (size_t i = 0; i < srcs.size(); i++)
+            repack_rows(plan, type, srcs[i], N_each, K, (int64_t)i * N_each, &st.buf[off_qs], &st.buf[off_qh], &st.buf[off_dm], &st.buf[off_w16]);
+        if (plan.bytes_w16) fix(&W.w16, off_w16);
+        if (plan.bytes_qs) fix(&W.qs, off_qs);
+        if (plan.bytes_qh) fix(&W.qh, off_qh);
+        if (plan.bytes_dm) fix(&W.dm, off_dm);
+        return true;
+    }
+
+    bool layers(const char * prefix, int n_layer, int h, int ff, std::vector<DevLayer> & L) {
+        L.resize(n_layer);
+        char b[96];
+        for (int i = 0; i < n_layer; i++) {
+            auto nm = [&](const char * what, const char * suf) {
+                snprintf(b, sizeof b, "%s.blk.%d.%s.%s", prefix, i, what, suf);
+                return std::string(b);
+            };
+            DevLayer & l = L[i];
+            if (!linear({nm("attn_q", "weight"), nm("attn_k", "weight"), nm("attn_v", "weight")}, l.qkv, h, h)) return false;
+            if (!vec_f32({nm("attn_q", "bias"), nm("attn_k", "bias"), nm("attn_v", "bias")}, &l.qkv_b, h)) return false;
+            if (!linear({nm("attn_out", "weight")}, l.o, h, h) || !vec_f32({nm("attn_out", "bias")}, &l.o_b, h)) return false;
+            // (sic) "ffn_down" is the h->ff projection, "ffn_up" the ff->h one (reference clip.cpp:510-511,572-573)
+            if (!linear({nm("ffn_down", "weight")}, l.ff1, h, ff) || !vec_f32({nm("ffn_down", "bias")}, &l.ff1_b, ff)) return false;
+            if (!linear({nm("ffn_up", "weight")}, l.ff2, ff, h) || !vec_f32({nm("ffn_up", "bias")}, &l.ff2_b, h)) return false;
+            if (!vec_f32({nm("ln1", "weight")}, &l.ln1_w, h) || !vec_f32({nm("ln1", "bias")}, &l.ln1_b, h)) return false;
+            if (!vec_f32({nm("ln2", "weight")}, &l.ln2_w, h) || !vec_f32({nm("ln2", "bias")}, &l.ln2_b, h)) return false;
+        }
+        return true;
+    }
+};
+
+bool kv_u32(const GgufFile & g, const std::string & key, int32_t & out, std::string & err) {
+    uint32_t v;
+    if (!g.get_u32(key, v)) { if (err.empty()) err = "key " + key + " not found in file"; return false; }
+    out = (int32_t)v;
+    return true;
+}
+
+}  // namespace
+
+clip_ctx * load_model(const char * fname, int verbosity, int device) {
+    GgufFile g;
+    std::string err;
+    if (!g.open(fname, err)) {
+        fprintf(stderr, "clip_model_load: %s\n", err.c_str());
+        return nullptr;
+    }
+    clip_ctx * ctx = new clip_ctx();
+    ctx->verbosity = verbosity;
+    ctx->path = fname;
+    auto fail = [&](const std::string & why) -> clip_ctx * {
+        fprintf(stderr, "clip_model_load: %s (%s)\n", why.c_str(), fname);
+        free_model(ctx);
+        return nullptr;
+    };
+
+    uint32_t ftype = 1;
+    if (!g.get_u32("general.file_type", ftype)) return fail("key general.file_type not found in file");
+    switch (ftype) {
+    case 0: case 1: case 2: case 3: case 6: case 7: case 8: break;
+    default: return fail("unrecognized file type " + std::to_string(ftype));
+    }
+    ctx->ftype = (int32_t)ftype;
+    if (!g.get_bool("clip.has_text_encoder", ctx->has_text_encoder)) return fail("key clip.has_text_encoder not found in file");
+    if (!g.get_bool("clip.has_vision_encoder", ctx->has_vision_encoder)) return fail("key clip.has_vision_encoder not found in file");
+    if (!g.get_bool("clip.use_gelu", ctx->use_gelu)) return fail("key clip.use_gelu not found in file");
+
+    if (verbosity >= 1) {
+        const GgufValue * name = g.find("general.name");
+        const GgufValue * desc = g.find("general.description");
+        if (name) printf("%s: model name:   %s\n", "clip_model_load", name->str.c_str());
+        if (desc) printf("%s: description:  %s\n", "clip_model_load", desc->str.c_str());
+        printf("%s: GGUF version: %u\n", "clip_model_load", g.version);
+        printf("%s: alignment:    %zu\n", "clip_model_load", (size_t)g.alignment);
+        printf("%s: n_tensors:    %zu\n", "clip_model_load", g.tensors.size());
+        printf("%s: n_kv:         %zu\n", "clip_model_load", g.kv.size());
+        printf("%s: ftype:        %s\n\n", "clip_model_load", ggml_type_name((int)ftype));
+    }
+    if (verbosity >= 3) {
+        for (size_t i = 0; i < g.kv.size(); i++) printf("%s: kv[%zu]: key = %s\n", "clip_model_load", i, g.kv[i].first.c_str());
+        for (size_t i = 0; i < g.tensors.size(); i++) {
+            const auto & t = g.tensors[i];
+            printf("%s: tensor[%zu]: n_dims = %d, name = %s, tensor_size=%zu, offset=%zu\n", "clip_model_load", i, t.n_dims,
+                   t.name.c_str(), t.nbytes, (size_t)t.offset);
+        }
+    }
+
+    Loader L(g);
+    std::string kerr;
+    if (ctx->has_text_encoder) {
+        auto & hp = ctx->text_hparams;
+        bool ok = kv_u32(g, "clip.text.embedding_length", hp.hidden_size, kerr) & kv_u32(g, "clip.text.attention.head_count", hp.n_head, kerr) &
+                  kv_u32(g, "clip.text.feed_forward_length", hp.n_intermediate, kerr) & kv_u32(g, "clip.text.block_count", hp.n_layer, kerr) &
+                  kv_u32(g, "clip.text.context_length", hp.num_positions, kerr) & kv_u32(g, "clip.text.projection_dim", hp.projection_dim, kerr);
+        if (!g.get_f32("clip.text.attention.layer_norm_epsilon", hp.eps)) { ok = false; if (kerr.empty()) kerr = "key clip.text.attention.layer_norm_epsilon not found in file"; }
+        const GgufValue * toks = g.find("tokenizer.ggml.tokens");
+        if (!toks || toks->type != GV_ARR || toks->elem_type != GV_STR) { ok = false; if (kerr.empty()) kerr = "key tokenizer.ggml.tokens not found in file"; }
+        if (!ok) return fail(kerr);
+        hp.n_vocab = (int32_t)toks->strs.size();
+        ctx->id_to_token = toks->strs;
+        ctx->token_to_id.reserve(toks->strs.size() * 2);
+        for (int32_t id = 0; id < hp.n_vocab; id++) {
+            ctx->token_to_id[toks->strs[id]] = id;   // later duplicates win, as with the reference's std::map assignment
+            ctx->max_token_len = std::max(ctx->max_token_len, toks->strs[id].size());
+        }
+        if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64)
+            return fail("unsupported text hparams (hidden/ff must be multiples of 64)");
+        if (verbosity >= 2) {
+            printf("\n%s: text model hparams\n", "clip_model_load");
+            printf("n_vocab            %d\nnum_positions      %d\nt_hidden_size      %d\nt_n_intermediate   %d\n", hp.n_vocab, hp.num_positions, hp.hidden_size, hp.n_intermediate);
+            printf("t_projection_dim   %d\nt_n_head           %d\nt_n_layer          %d\n", hp.projection_dim, hp.n_head, hp.n_layer);
+        }
+        DevTower & T = ctx->text;
+        const int h = hp.hidden_size;
+        if (!L.raw("t.token_embd.weight", &T.tok_raw, &T.tok_type, h, hp.n_vocab) ||
+            !L.table_f32("t.position_embd.weight", &T.pos, h, hp.num_positions) ||
+            !L.vec_f32({"t.post_ln.weight"}, &T.post_ln_w, h) || !L.vec_f32({"t.post_ln.bias"}, &T.post_ln_b, h) ||
+            !L.linear({"text_projection.weight"}, T.proj, h, hp.projection_dim) ||
+            !L.layers("t", hp.n_layer, h, hp.n_intermediate, T.layers))
+            return fail(L.err);
+    }
+    if (ctx->has_vision_encoder) {
+        auto & hp = ctx->vision_hparams;
+        bool ok = kv_u32(g, "clip.vision.embedding_length", hp.hidden_size, kerr) & kv_u32(g, "clip.vision.attention.head_count", hp.n_head, kerr) &
+                  kv_u32(g, "clip.vision.feed_forward_length", hp.n_intermediate, kerr) & kv_u32(g, "clip.vision.block_count", hp.n_layer, kerr) &
+                  kv_u32(g, "clip.vision.image_size", hp.image_size, kerr) & kv_u32(g, "clip.vision.patch_size", hp.patch_size, kerr) &
+                  kv_u32(g, "clip.vision.projection_dim", hp.projection_dim, kerr);
+        if (!g.get_f32("clip.vision.attention.layer_norm_epsilon", hp.eps)) { ok = false; if (kerr.empty()) kerr = "key clip.vision.attention.layer_norm_epsilon not found in file"; }
+        const GgufValue * mean = g.find("clip.vision.image_mean");
+        const GgufValue * stdv = g.find("clip.vision.image_std");
+        if (!mean || !stdv || mean->type != GV_ARR || stdv->type != GV_ARR || mean->elem_type != GV_F32 || stdv->elem_type != GV_F32 ||
+            mean->count < 3 || stdv->count < 3) { ok = false; if (kerr.empty()) kerr = "key clip.vision.image_mean/std not found in file"; }
+        if (!ok) return fail(kerr);
+        memcpy(ctx->image_mean, mean->raw.data(), 12);
+        memcpy(ctx->image_std, stdv->raw.data(), 12);
+        if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64 ||
+            hp.patch_size <= 0 || hp.image_size % hp.patch_size)
+            return fail("unsupported vision hparams (hidden/ff must be multiples of 64)");
+        if (verbosity >= 2) {
+            printf("\n%s: vision model hparams\n", "clip_model_load");
+            printf("image_size         %d\npatch_size         %d\nv_hidden_size      %d\nv_n_intermediate   %d\n", hp.image_size, hp.patch_size, hp.hidden_size, hp.n_intermediate);
+            printf("v_projection_dim   %d\nv_n_head           %d\nv_n_layer          %d\n", hp.projection_dim, hp.n_head, hp.n_layer);
+        }
+        DevTower & V = ctx->vision;
+        const int h = hp.hidden_size, P = hp.patch_size, Gd = hp.image_size / P, T = Gd * Gd + 1;
+        const GgufTensorInfo * pe = L.need("v.patch_embd.weight");
+        if (!pe) return fail(L.err);
+        if (pe->type != GT_F16 && pe->type != GT_F32) return fail("v.patch_embd.weight must be f16");
+        if (!L.linear({"v.patch_embd.weight"}, V.patch, 3 * P * P, h, /*as_conv=*/true) ||
+            !L.vec_f32({"v.class_embd"}, &V.class_embd, h) ||
+            !L.table_f32("v.position_embd.weight", &V.pos, h, T) ||
+            !L.vec_f32({"v.pre_ln.weight"}, &V.pre_ln_w, h) || !L.vec_f32({"v.pre_ln.bias"}, &V.pre_ln_b, h) ||
+            !L.vec_f32({"v.post_ln.weight"}, &V.post_ln_w, h) || !L.vec_f32({"v.post_ln.bias"}, &V.post_ln_b, h) ||
+            !L.linear({"visual_projection.weight"}, V.proj, h, hp.projection_dim) ||
+            !L.layers("v", hp.n_layer, h, hp.n_intermediate, V.layers))
+            return fail(L.err);
+    }
+    if (verbosity >= 1) {
+        printf("%s: text_encoder:   %d\n", "clip_model_load", ctx->has_text_encoder);
+        printf("%s: vision_encoder: %d\n", "clip_model_load", ctx->has_vision_encoder);
+        printf("%s: model size:     %.2f MB (HBM image, repacked)\n", "clip_model_load", L.st.buf.size() / 1024.0 / 1024.0);
+    }
+
+    // ---- device ----
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    if (ndev <= 0) {
+        (void)hipGetLastError();
+        const char * allow = getenv("CLIP_AMD_ALLOW_NO_DEVICE");
+        if (allow && allow[0] == '1') {
+            if (verbosity >= 1) fprintf(stderr, "clip_model_load: no HIP device — host-only context (tokenizer / preprocessing only; encoders will fail)\n");
+            ctx->device = -1;
+            return ctx;
+        }
+        return fail("no HIP device available: this library has no CPU fallback (set CLIP_AMD_ALLOW_NO_DEVICE=1 for a host-only context)");
+    }
+    if (device < 0 || device >= ndev) return fail("invalid HIP device ordinal " + std::to_string(device));
+    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    ctx->stream = ctx->own_stream;
+    ctx->weights_bytes = L.st.buf.size() + 256;
+    if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");
+    if (hipMemcpy(ctx->weights_base, L.st.buf.data(), L.st.buf.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("weight upload failed");
+    for (const Fix & f : L.fixes) *f.slot = (const uint8_t *)ctx->weights_base + f.off;
+    if (verbosity >= 1) printf("\n%s: %zu MB of HBM allocated for weights on device %d\n", "clip_model_load", ctx->weights_bytes / 1024 / 1024, device);
+    return ctx;
+}
+
+void free_model(clip_ctx * ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+        for (auto & p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        if (ctx->ws.base) (void)hipFree(ctx->ws.base);
+        if (ctx->weights_base) (void)hipFree(ctx->weights_base);
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    }
+    delete ctx;
+}
+
+// Test hook: repack one raw ggml-layout weight through the production path and upload it.
+bool repack_for_test(int type, const void * w_raw, int64_t N, int64_t K, DevWeight & W, void ** dev_base) {
+    RepackPlan pl;
+    std::string err;
+    if (!plan_repack(type, N, K, pl, err)) { fprintf(stderr, "repack_for_test: %s\n", err.c_str()); return false; }
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_w16 = 0, o_qs = up(pl.bytes_w16), o_qh = o_qs + up(pl.bytes_qs), o_dm = o_qh + up(pl.bytes_qh);
+    const size_t total = o_dm + up(pl.bytes_dm) + 256;
+    std::vector<uint8_t> host(total, 0);
+    repack_rows(pl, type, (const uint8_t *)w_raw, N, K, 0, &host[o_qs], &host[o_qh], &host[o_dm], &host[o_w16]);
+    void * base = nullptr;
+    if (hipMalloc(&base, total) != hipSuccess) return false;
+    if (hipMemcpy(base, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(base); return false; }
+    W = pl.W;
+    const uint8_t * b = (const uint8_t *)base;
+    if (pl.bytes_w16) W.w16 = b + o_w16;
+    if (pl.bytes_qs) W.qs = b + o_qs;
+    if (pl.bytes_qh) W.qh = b + o_qh;
+    if (pl.bytes_dm) W.dm = b + o_dm;
+    *dev_base = base;
+    return true;
+}
+
+}  // namespace clipamd

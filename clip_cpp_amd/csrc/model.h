@@ -1,0 +1,118 @@
+// model.h — clip_ctx: host-side model state + HBM-resident weights + forward workspace.
+//
+// Mirrors what reference clip.cpp keeps in `struct clip_ctx` (clip.cpp:240-253), `clip_text_model`
+// (:192-205), `clip_vision_model` (:207-224) and `clip_layer` (:164-190), re-laid-out for the GPU:
+// weights are uploaded once at load (clip_model_load, reference :334-596) in the GEMM-friendly
+// repacked format of kernels.h, q/k/v are fused into one [3h][h] weight, and the fixed-size arenas of
+// reference :261-331 are replaced by a workspace sized from hparams x batch.
+#pragma once
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/clip.h"
+#include "gguf.h"
+#include "kernels.h"
+
+namespace clipamd {
+
+struct DevLayer {
+    DevWeight qkv, o, ff1, ff2;
+    const float *qkv_b = nullptr, *o_b = nullptr, *ff1_b = nullptr, *ff2_b = nullptr;
+    const float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+};
+
+struct DevTower {
+    std::vector<DevLayer> layers;
+    const float * pos = nullptr;          // [T][h] f32 (dequantised once; ggml_get_rows semantics)
+    const float *post_ln_w = nullptr, *post_ln_b = nullptr;
+    DevWeight proj;
+    // vision only
+    DevWeight patch;                      // [h][3*P*P] f16, k = (c,ky,kx)
+    const float * class_embd = nullptr;
+    const float *pre_ln_w = nullptr, *pre_ln_b = nullptr;
+    // text only
+    const void * tok_raw = nullptr;       // token_embd in its ggml block layout
+    int tok_type = 0;
+};
+
+struct ProfEntry {
+    double ms = 0;
+    int64_t launches = 0;
+    double flops = 0;
+    double bytes = 0;
+};
+
+struct Workspace {
+    void * base = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace clipamd
+
+// The opaque handle of the C API (reference clip.h:8).
+struct clip_ctx {
+    bool has_text_encoder = false;
+    bool has_vision_encoder = false;
+    bool use_gelu = false;
+    int32_t ftype = 1;
+    clip_text_hparams text_hparams{};
+    clip_vision_hparams vision_hparams{};
+    float image_mean[3] = {0, 0, 0};
+    float image_std[3] = {1, 1, 1};
+
+    // tokenizer (reference clip_vocab, clip.cpp:149-158)
+    std::vector<std::string> id_to_token;
+    std::unordered_map<std::string, int32_t> token_to_id;
+    size_t max_token_len = 0;
+
+    // device state
+    int device = -1;                 // -1: host-only ctx (no encoders)
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;    // stream in use (own or user-provided)
+    void * weights_base = nullptr;   // one HBM allocation holding every tensor
+    size_t weights_bytes = 0;
+    clipamd::DevTower vision, text;
+    clipamd::Workspace ws;           // activations, grown on demand
+    void * pinned = nullptr;         // pinned host staging
+    size_t pinned_bytes = 0;
+
+    // profiling (HIP events on the ctx stream)
+    bool profiling = false;
+    struct PendingEvent { hipEvent_t a, b; std::string tag; double flops, bytes; };
+    std::vector<PendingEvent> pending;
+    std::map<std::string, clipamd::ProfEntry> prof;
+
+    int verbosity = 0;
+    std::string path;
+};
+
+namespace clipamd {
+
+// load.cpp
+clip_ctx * load_model(const char * fname, int verbosity, int device);
+void free_model(clip_ctx * ctx);
+bool repack_for_test(int type, const void * w_raw, int64_t N, int64_t K, DevWeight & W, void ** dev_base);
+
+// forward.cpp  (device pointers; asynchronous on ctx->stream)
+bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize);
+bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets, int n_texts, float * d_out,
+                         bool normalize);
+bool ensure_workspace(clip_ctx * ctx, size_t bytes);
+bool ensure_pinned(clip_ctx * ctx, size_t bytes);
+void prof_collect(clip_ctx * ctx);
+
+// host pieces
+bool tokenize_text(const clip_ctx * ctx, const char * text, std::vector<int32_t> & out);            // tokenizer.cpp
+bool preprocess_image(const clip_ctx * ctx, const clip_image_u8 * img, clip_image_f32 * res);      // preprocess.cpp
+bool load_image_file(const char * fname, clip_image_u8 * img);                                      // image_io.cpp
+
+// quant.cpp — host codecs for the ggml block formats
+void dequantize_row(int type, const void * src, float * dst, int64_t k);
+size_t quantize_rows(int type, const float * src, void * dst, int64_t nrows, int64_t k);
+uint16_t f32_to_f16_bits(float x);
+float f16_bits_to_f32(uint16_t h);
+
+}  // namespace clipamd

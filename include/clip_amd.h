@@ -1,0 +1,78 @@
+/* clip_amd.h — MI355X-specific extensions of the clip.h C ABI.
+ *
+ * Everything here is ADDITIVE to the reference API (include/clip.h).  Plain C
+ * ABI: pointers + sizes only, no torch / HIP types in signatures (a HIP stream
+ * is passed as void*).  Device pointers are raw HBM addresses on the ctx's
+ * device (e.g. torch.Tensor.data_ptr()).
+ */
+#ifndef CLIP_AMD_H
+#define CLIP_AMD_H
+
+#include "clip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of visible HIP devices (0 when there is no GPU / driver). */
+int clip_amd_device_count(void);
+
+/* Like clip_model_load (reference clip.cpp:334) but on an explicit device ordinal.
+ * clip_model_load uses $CLIP_AMD_DEVICE, else $LOCAL_RANK, else device 0. */
+struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int device);
+
+/* Which device a ctx lives on (-1: host-only ctx, see CLIP_AMD_ALLOW_NO_DEVICE in DESIGN.md). */
+int clip_amd_ctx_device(const struct clip_ctx * ctx);
+
+/* Bind all subsequent launches of this ctx to an existing HIP stream (e.g. torch's current
+ * stream, as an integer handle).  NULL restores the ctx's own stream. */
+void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream);
+
+/* Device-resident form of clip_image_batch_encode (reference clip.cpp:1247-1523):
+ * d_imgs  : B x [S,S,3] float32 interleaved RGB, already preprocessed, in HBM
+ * d_out   : B x projection_dim float32 in HBM
+ * Asynchronous on the ctx stream; no host<->device copies. */
+bool clip_amd_image_batch_encode_device(struct clip_ctx * ctx, const float * d_imgs, int batch, float * d_out,
+                                        bool normalize);
+
+/* Batched text encoding ("next" row §8f-2; per-text semantics identical to
+ * clip_text_encode, reference clip.cpp:1016-1233).  Texts are ragged:
+ * tokens[i].data holds tokens[i].size ids incl. BOS/EOS.  vec: [n_texts][projection_dim]. */
+bool clip_text_batch_encode(const struct clip_ctx * ctx, const int n_threads, const struct clip_tokens * tokens,
+                            size_t n_texts, float * vec, const bool normalize);
+
+/* Device-resident batched text encode: d_ids = concatenated ids (int32, HBM),
+ * h_offsets = n_texts+1 prefix offsets (HOST memory), d_out [n_texts][proj] in HBM. */
+bool clip_amd_text_batch_encode_device(struct clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets,
+                                       int n_texts, float * d_out, bool normalize);
+
+/* Block until everything queued on the ctx stream has finished. */
+void clip_amd_synchronize(struct clip_ctx * ctx);
+
+/* Per-kernel-family accumulated device time (ms) since the last reset, measured with HIP events
+ * on the ctx stream when profiling is enabled.  families: 0 gemm, 1 attention, 2 layernorm,
+ * 3 other.  launches[] receives launch counts.  Returns number of families written. */
+void clip_amd_profile_enable(struct clip_ctx * ctx, bool on);
+int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches, int cap, bool reset);
+/* Text report, one line per (kernel family : MxNxK) tag: "tag launches total_ms flops bytes".
+ * Returns the number of bytes needed (call with buf == NULL to size the buffer). */
+int clip_amd_profile_report(struct clip_ctx * ctx, char * buf, int cap, bool reset);
+
+/* ---- kernel-level test hooks (used by tests/ only; host pointers, synchronous) ----
+ * Y[M,N] = X[M,K] . W[N,K]^T (+bias) through the production dequant-GEMM kernel.
+ * w_raw is the tensor in its GGUF/ggml block layout (type: ggml type id 0,1,2,3,6,7,8).
+ * epilogue: 0 plain f32 out, 1 f16 out (returned widened to f32), 2 gelu->f16, 3 quick-gelu->f16,
+ *           4 residual: Y = resid + X.W^T + bias (f32).  tile: 0 auto, else BM*1000+BN. */
+int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M,
+                       const float * bias, const float * resid, float * y, int epilogue, int tile);
+/* y = LayerNorm(x)*w + b, rows x h. out_f16 != 0 rounds the result through fp16. */
+int clip_amd_test_layernorm(const float * x, const float * w, const float * b, float eps, int64_t rows, int64_t h,
+                            float * y, int out_f16);
+/* Multi-head attention over nseq sequences of length T each: qkv [nseq*T][3h] (q pre-scaled), out [nseq*T][h]. */
+int clip_amd_test_attention(const float * qkv, int nseq, int T, int h, int n_head, int causal, float * out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CLIP_AMD_H */

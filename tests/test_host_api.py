@@ -1,0 +1,208 @@
+"""CPU tier: the C-ABI library loads, exports the whole clip.h / clip_amd.h surface, and its host-side
+pieces (GGUF reader, tokenizer, preprocessing, quantizer, scoring) agree with the oracle.  No GPU compute."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import fixtures, ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
+    return [n for n in names if n not in ("defined",)]
+
+
+def test_library_exports_every_declared_symbol(clip_lib):
+    L = clip_lib.lib()
+    declared = set(_declared_functions("clip.h")) | set(_declared_functions("clip_amd.h")) | set(_declared_functions("ggml/ggml.h"))
+    assert len(declared) >= 35
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, "libclip.so does not export: %s" % missing
+    assert set(clip_lib.API_SYMBOLS) <= declared and set(clip_lib.AMD_SYMBOLS) <= declared
+    # the stub libggml.so the reference's ctypes binding dlopens
+    g = C.CDLL(os.path.join(os.path.dirname(clip_lib.LIB_PATH), "libggml.so"))
+    g.ggml_time_init()
+    assert g.ggml_time_us() >= 0
+
+
+def test_struct_layouts_match_reference_header(clip_lib):
+    assert C.sizeof(clip_lib.ClipTextHparams) == 32 and C.sizeof(clip_lib.ClipVisionHparams) == 32
+    assert C.sizeof(clip_lib.ClipTokens) == 16
+    assert C.sizeof(clip_lib.ClipImageU8) == 24 and C.sizeof(clip_lib.ClipImageF32) == 24
+
+
+def test_reference_style_c_caller_compiles_and_links(clip_lib, tmp_path):
+    """A plain-C translation unit written against include/clip.h (same calls as the reference's examples/simple.c)
+    compiles and links against libclip.so unchanged."""
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include "clip.h"
+#include <stdio.h>
+int main(int argc, char ** argv) {
+    ggml_time_init();
+    if (argc < 2) { printf("usage\n"); return 0; }
+    struct clip_ctx * ctx = clip_model_load(argv[1], 0);
+    if (!ctx) { printf("no ctx\n"); return 3; }
+    struct clip_vision_hparams * hp = clip_get_vision_hparams(ctx);
+    printf("proj=%d t=%lld\n", hp->projection_dim, (long long)ggml_time_us());
+    struct clip_tokens tokens;
+    if (!clip_tokenize(ctx, "a photo of a cat", &tokens)) return 4;
+    printf("ntok=%zu\n", tokens.size);
+    float a[4] = {1,2,3,4}, b[4] = {1,1,1,1};
+    printf("sim=%g\n", clip_similarity_score(a, b, 4));
+    clip_free(ctx);
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(clip_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
+                           "-lclip", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert "usage" in out
+
+
+@pytest.fixture(scope="module")
+def tiny_ctx(clip_lib, fixture_cache, host_only_env):
+    path = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    return clip_lib.Clip(path, verbosity=0), ref.OracleModel(path)
+
+
+def test_model_load_reads_hparams(tiny_ctx):
+    c, o = tiny_ctx
+    v, t = c.vision_config, c.text_config
+    assert (v["image_size"], v["patch_size"], v["hidden_size"], v["n_intermediate"], v["projection_dim"], v["n_head"], v["n_layer"]) == (32, 8, 64, 128, 32, 2, 2)
+    assert (t["n_vocab"], t["num_positions"], t["hidden_size"], t["n_head"], t["n_layer"]) == (49408, 77, 64, 2, 2)
+    assert abs(v["eps"] - 1e-5) < 1e-12
+
+
+def test_model_load_failures_return_null_not_throw(clip_lib, tmp_path, host_only_env):
+    L = clip_lib.lib()
+    assert not L.clip_model_load(b"/nonexistent/file.gguf", 0)
+    bad = tmp_path / "bad.gguf"
+    bad.write_bytes(b"GGUF" + b"\x02\x00\x00\x00" + b"\xff" * 40)
+    assert not L.clip_model_load(os.fsencode(str(bad)), 0)
+    junk = tmp_path / "junk.gguf"
+    junk.write_bytes(b"not a gguf file at all, sorry........")
+    assert not L.clip_model_load(os.fsencode(str(junk)), 0)
+    # truncated real file
+    src = fixtures.cached_model("/tmp/clip_amd_fixtures", "tiny", "q4_0")
+    data = open(src, "rb").read()
+    tr = tmp_path / "trunc.gguf"
+    tr.write_bytes(data[: len(data) // 2])
+    assert not L.clip_model_load(os.fsencode(str(tr)), 0)
+
+
+def test_no_device_means_no_context_unless_opted_in(clip_lib, fixture_cache):
+    """The product must fail loudly without a HIP device: no silent CPU fallback."""
+    if clip_lib.device_count() > 0:
+        pytest.skip("GPU present")
+    path = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    env = dict(os.environ)
+    env.pop("CLIP_AMD_ALLOW_NO_DEVICE", None)
+    code = "import clip_cpp_amd as c; L=c.lib(); import sys; sys.exit(0 if not L.clip_model_load(%r.encode(),0) else 1)" % path
+    r = subprocess.run(["python", "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "no HIP device" in r.stderr
+
+
+def test_host_only_context_refuses_to_encode(tiny_ctx, clip_lib):
+    if clip_lib.device_count() > 0:
+        pytest.skip("GPU present")
+    c, o = tiny_ctx
+    assert c.device == -1
+    with pytest.raises(RuntimeError):
+        c.encode_images(np.zeros((1, 32, 32, 3), dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        c.encode_text([49406, 5, 49407])
+
+
+TEXTS = ["a photo of a cat", "", " ", "  leading  spaces ", "dog's 42!!", "isn't it're've'm'll'd", "tab\there\nnew", "x  ", "  ",
+         "1234567 89", "snowman ☃ café", "'", "''s", " 's", "a\t\tb", "hello   world  ", "!@#$%^&*()", "A B  C   D"]
+
+
+def test_tokenizer_bit_exact_vs_oracle(tiny_ctx):
+    c, o = tiny_ctx
+    for t in TEXTS:
+        assert c.tokenize(t) == list(o.tokenize(t)), repr(t)
+
+
+def test_tokenizer_fuzz_vs_std_regex(tiny_ctx):
+    """Hand-written scanner == std::regex restatement on random byte soup (bit-exact ids)."""
+    c, o = tiny_ctx
+    rng = np.random.default_rng(123)
+    alphabet = list("abetz AB09 '!?.,\t\n-") + ["'s", "'re", "  ", " 'll", "é"]
+    for _ in range(400):
+        n = int(rng.integers(0, 24))
+        s = "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), n))
+        assert c.tokenize(s) == list(o.tokenize(s)), repr(s)
+
+
+def test_preprocess_bit_exact_vs_oracle(tiny_ctx):
+    c, o = tiny_ctx
+    rng = np.random.default_rng(9)
+    for (ny, nx) in ((50, 60), (32, 32), (97, 41), (33, 200), (480, 640)):
+        img = rng.integers(0, 256, size=(ny, nx, 3), dtype=np.uint8)
+        a = c.preprocess(img)
+        b = o.preprocess(img)
+        assert np.array_equal(a, b), (ny, nx)
+
+
+def test_batch_preprocess_threads(tiny_ctx, clip_lib):
+    c, o = tiny_ctx
+    L = clip_lib.lib()
+    rng = np.random.default_rng(10)
+    imgs = [rng.integers(0, 256, size=(40 + 3 * i, 50 + i, 3), dtype=np.uint8) for i in range(5)]
+    arr = (clip_lib.ClipImageU8 * 5)()
+    for i, im in enumerate(imgs):
+        arr[i] = clip_lib.ClipImageU8(im.shape[1], im.shape[0], im.ctypes.data_as(C.POINTER(C.c_uint8)), im.size)
+    inb = clip_lib.ClipImageU8Batch(C.cast(arr, C.POINTER(clip_lib.ClipImageU8)), 5)
+    outarr = (clip_lib.ClipImageF32 * 5)()
+    outb = clip_lib.ClipImageF32Batch(C.cast(outarr, C.POINTER(clip_lib.ClipImageF32)), 0)
+    L.clip_image_batch_preprocess(c.ctx, 3, C.byref(inb), C.byref(outb))
+    assert outb.size == 5
+    for i, im in enumerate(imgs):
+        got = np.ctypeslib.as_array(outarr[i].data, shape=(32, 32, 3))
+        assert np.array_equal(got, o.preprocess(im))
+        L.clip_image_f32_clean(C.byref(outarr[i]))
+
+
+def test_scoring_helpers_match_reference_semantics(clip_lib):
+    L = clip_lib.lib()
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal(512).astype(np.float32)
+    b = rng.standard_normal(512).astype(np.float32)
+    got = L.clip_similarity_score(a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)), 512)
+    assert got == ref.similarity(a, b)   # same sequential f32 accumulation -> bit-exact
+    x = rng.standard_normal(37).astype(np.float32)
+    x[5] = x[9]  # tie
+    s0, i0 = ref.softmax_with_sorting(x)
+    arr = x.copy()
+    s1 = np.empty(37, dtype=np.float32)
+    i1 = np.empty(37, dtype=np.int32)
+    assert L.softmax_with_sorting(arr.ctypes.data_as(C.POINTER(C.c_float)), 37, s1.ctypes.data_as(C.POINTER(C.c_float)),
+                                  i1.ctypes.data_as(C.POINTER(C.c_int)))
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1)
+    assert abs(s1.sum() - 1.0) < 1e-5 and np.all(np.diff(s1) <= 0)
+
+
+@pytest.mark.parametrize("ftype", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_quantizer_bit_exact_vs_oracle_codecs(clip_lib, tmp_path, fixture_cache, ftype):
+    """clip_model_quantize (product codecs) re-emits the f32 GGUF with bit-identical blocks to the oracle's restatement
+    of quantize_row_q*_reference, and only 2-D '*weight' tensors are touched (clip.cpp:1711-1739)."""
+    src = fixtures.cached_model(fixture_cache, "tiny", "f32", text=False, vision=True)
+    dst = str(tmp_path / ("q_%s.gguf" % ftype))
+    assert clip_lib.quantize(src, dst, ref.GGML_TYPES[ftype])
+    expect = fixtures.cached_model(fixture_cache, "tiny", ftype, text=False, vision=True)
+    a, b = ref.OracleModel(dst), ref.OracleModel(expect)
+    assert a.info == b.info and a.info["ftype"] == ref.GGML_TYPES[ftype]
+    imgs = fixtures.synthetic_images(2, 32)
+    assert np.array_equal(a.image_batch_encode(imgs), b.image_batch_encode(imgs))
+    assert not clip_lib.quantize(src, dst, 5)  # invalid itype

@@ -1,0 +1,149 @@
+"""Pins the CPU oracle (oracle/clip_oracle.cpp): HF CLIPModel goldens, codec KATs, PIL resampler."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fixtures, ref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("config", ["tiny", "tiny14"])
+def test_oracle_matches_hf_clipmodel(config, tmp_path, oracle_lib):
+    """oracle(ideal, f32 weights) == transformers.CLIPModel on the same seeded weights (oracle/hf_crosscheck.py)."""
+    g = np.load(os.path.join(GOLDEN, "hf_%s.npz" % config))
+    path = str(tmp_path / "m.gguf")
+    master = fixtures.make_model(path, config, "f32", seed=int(g["seed"]), keep_master=True)
+    from oracle.hf_crosscheck import weights_checksum
+    assert weights_checksum(master) == str(g["checksum"]), "numpy RNG stream changed: regenerate tests/golden with oracle/hf_crosscheck.py"
+    m = ref.OracleModel(path)
+    e = m.image_batch_encode(g["images"], normalize=False, mode=ref.MODE_IDEAL)
+    np.testing.assert_allclose(e, g["image_embeds"], atol=2e-6, rtol=0)
+    for i in range(4):
+        t = m.text_encode(g["ids_%d" % i], normalize=False, mode=ref.MODE_IDEAL)
+        np.testing.assert_allclose(t, g["text_embeds_%d" % i], atol=2e-6, rtol=0)
+    # faithful (ggml numerics) mode with f32 weights differs only by the fp16 exp/GELU tables and fp16 im2col
+    e0 = m.image_batch_encode(g["images"], normalize=True, mode=ref.MODE_FAITHFUL)
+    e1 = m.image_batch_encode(g["images"], normalize=True, mode=ref.MODE_IDEAL)
+    assert np.all(1.0 - (e0 * e1).sum(1) < 1e-5)
+
+
+def _kat_block():
+    # 32 values with a unique largest-magnitude element so d is unambiguous
+    x = np.array([(-1) ** i * (i + 1) / 32.0 for i in range(32)], dtype=np.float32)
+    return x
+
+
+def test_codec_known_answers(oracle_lib):
+    """Hand-derived known answers for the block formats."""
+    x = _kat_block()[None, :]
+    # q8_0: d = amax/127 = 1/127 ; q_i = round(x_i * 127)
+    raw = ref.quantize(8, x)
+    assert raw.size == 34
+    d = np.frombuffer(raw[:2].tobytes(), dtype=np.float16)[0]
+    assert d == np.float16(np.float32(1.0) / np.float32(127.0))
+    q = np.frombuffer(raw[2:].tobytes(), dtype=np.int8)
+    exp_q = np.array([int(np.floor(abs(v) * 127 + 0.5)) * (1 if v > 0 else -1) for v in x[0].astype(np.float64)], dtype=np.int8)
+    # x_i*id is evaluated in f32: allow the off-by-one only where the product sits on a rounding boundary
+    assert np.all(np.abs(q.astype(int) - exp_q.astype(int)) <= 1) and q[31] == 127 * (-1) ** 31
+    # q4_0: max = signed value of the largest magnitude = -1.0 (i=31) -> d = max / -8 = 0.125
+    raw = ref.quantize(2, x)
+    assert raw.size == 18
+    d = np.frombuffer(raw[:2].tobytes(), dtype=np.float16)[0]
+    assert float(d) == 0.125
+    qs = raw[2:]
+    lo, hi = qs & 0x0F, qs >> 4
+    # element 31 (= hi nibble of byte 15) is -1.0 -> -1/0.125 + 8.5 = 0.5 -> q = 0 ; element 30 -> +0.96875*8+8.5=16.25 -> min(15,16)=15
+    assert hi[15] == 0 and hi[14] == 15 and lo[14] == 12  # elem 14: 0.46875*8+8.5=12.25 -> 12
+    deq = ref.dequantize(2, raw, 1, 32)[0]
+    assert deq[31] == -1.0 and np.all(np.abs(deq - x[0]) <= 0.125 + 1e-6)
+    # q4_1: min=-1.0, max=31/32 -> d = (max-min)/15
+    raw = ref.quantize(3, x)
+    d = np.frombuffer(raw[:2].tobytes(), dtype=np.float16)[0]
+    m = np.frombuffer(raw[2:4].tobytes(), dtype=np.float16)[0]
+    assert float(m) == -1.0 and d == np.float16((np.float32(31 / 32) + np.float32(1.0)) / np.float32(15))
+    # q5_0 / q5_1 : 5th bit plane round-trips
+    for tid, step in ((6, 1.0 / 16), (7, (31 / 32 + 1) / 31)):
+        raw = ref.quantize(tid, x)
+        deq = ref.dequantize(tid, raw, 1, 32)[0]
+        assert np.all(np.abs(deq - x[0]) <= step * 0.51 + 2e-3), tid
+    # block sizes
+    for name, nb in (("q4_0", 18), ("q4_1", 20), ("q5_0", 22), ("q5_1", 24), ("q8_0", 34), ("f16", 64), ("f32", 128)):
+        assert ref.row_bytes(ref.GGML_TYPES[name], 32) == nb
+
+
+def test_fp16_conversion_matches_numpy(oracle_lib):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(2000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 100, 7e4)])
+    xs = np.concatenate([xs, np.array([0.0, -0.0, 65504.0, 65520.0, 1e-7, 6.1e-5, 5.96e-8, 2.98e-8], dtype=np.float32)])
+    L = ref.lib()
+    with np.errstate(over="ignore"):
+        expect = xs.astype(np.float16).view(np.uint16)
+    got = np.array([L.orc_f2h(float(v)) for v in xs], dtype=np.uint16)
+    assert np.array_equal(got, expect)
+    back = np.array([L.orc_h2f(int(h)) for h in range(0, 65536, 7)], dtype=np.float32)
+    ref_back = np.arange(0, 65536, 7, dtype=np.uint16).view(np.float16).astype(np.float32)
+    ok = (back == ref_back) | (np.isnan(back) & np.isnan(ref_back))
+    assert ok.all()
+
+
+def test_mul_mat_faithful_close_to_ideal(oracle_lib):
+    """ggml-numerics mul_mat (q8 activation quantisation) stays within the expected noise of the f32 product."""
+    rng = np.random.default_rng(3)
+    N, K, M = 96, 256, 40
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    for name in ("f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"):
+        tid = ref.GGML_TYPES[name]
+        raw = ref.quantize(tid, W)
+        Wd = ref.dequantize(tid, raw, N, K)
+        y0 = ref.mul_mat(tid, raw, N, K, X, ref.MODE_FAITHFUL)
+        y1 = ref.mul_mat(tid, raw, N, K, X, ref.MODE_IDEAL)
+        np.testing.assert_allclose(y1, X @ Wd.T, atol=1e-4, rtol=1e-4)
+        rel = np.abs(y0 - y1).max() / np.abs(y1).max()
+        assert rel < (2e-3 if name == "f16" else 3e-2), (name, rel)
+
+
+def test_preprocess_matches_pil(oracle_lib, tmp_path):
+    """The bicubic resampler restated from clip.cpp:728-927 follows PIL's Resample.c (BICUBIC, antialias)."""
+    PIL = pytest.importorskip("PIL.Image")
+    path = str(tmp_path / "v.gguf")
+    fixtures.make_model(path, "b32", "f16", text=False, vision=True, seed=5) if False else fixtures.make_model(
+        path, dict(v=dict(S=224, P=32, h=64, L=1, nh=1, ff=64, proj=64), t=None), "f32", text=False, vision=True, seed=5)
+    m = ref.OracleModel(path)
+    rng = np.random.default_rng(1)
+    # smooth synthetic photo-like image, 600x500 (w x h) like tests/red_apple.jpg
+    yy, xx = np.mgrid[0:500, 0:600]
+    img = np.stack([(np.sin(xx / 37.0) * 0.5 + 0.5) * 255, (np.cos(yy / 23.0) * 0.5 + 0.5) * 255,
+                    ((xx + yy) % 256)], axis=-1)
+    img = np.clip(img + rng.normal(0, 4, img.shape), 0, 255).astype(np.uint8)
+    out = m.preprocess(img)
+    S = 224
+    # PIL: resize shorter side to 224 (bicubic), centre crop, normalise
+    pim = PIL.fromarray(img)
+    scale = min(600, 500) / S
+    nx3, ny3 = int(600 / scale + 0.5), int(500 / scale + 0.5)
+    r = np.asarray(pim.resize((nx3, ny3), PIL.BICUBIC), dtype=np.float32)
+    xo, yo = (nx3 - S) // 2, (ny3 - S) // 2
+    r = r[yo:yo + S, xo:xo + S, :]
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    expect = (r / 255.0 - mean) / std
+    # PIL rounds to uint8 after each pass; the reference keeps floats: differences stay within ~1.5 grey levels
+    assert np.abs(out - expect).max() < 1.6 / 255.0 / std.min() * 1.0 + 1e-3
+    assert np.abs(out - expect).mean() < 0.6 / 255.0 / std.min()
+
+
+def test_tokenizer_known_answers(oracle_lib, fixture_cache):
+    path = fixtures.cached_model(fixture_cache, "tiny", "f32", text=True, vision=False)
+    m = ref.OracleModel(path)
+    vocab = fixtures.synthetic_vocab()
+    tid = {t: i for i, t in enumerate(vocab)}
+    # whole-word hits
+    assert list(m.tokenize("a photo of a cat")) == [49406, tid["a</w>"], tid["photo</w>"], tid["of</w>"], tid["a</w>"], tid["cat</w>"], 49407]
+    # greedy longest-match fallback: "tee" -> "te","e" (no </w> on pieces) ; leading space is an unknown byte and skipped
+    assert list(m.tokenize(" tee")) == [49406, tid["te"], tid["e"], 49407]
+    # contraction split + digits + punctuation run
+    assert list(m.tokenize("dog's 42!!")) == [49406, tid["dog</w>"], tid["'"], tid["s"], tid["42</w>"], tid["!"], tid["!"], 49407]
+    assert list(m.tokenize("")) == [49406, 49407]
