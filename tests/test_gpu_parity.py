@@ -154,7 +154,9 @@ def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
     host = clip.encode_images(imgs)
     d_in = torch.from_numpy(imgs).cuda()
     d_out = torch.empty((7, 32), dtype=torch.float32, device="cuda")
-    clip.set_stream(torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    clip.set_stream(st.cuda_stream)
     clip.encode_images_device(d_in.data_ptr(), 7, d_out.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), host)
