@@ -206,3 +206,22 @@ def test_quantizer_bit_exact_vs_oracle_codecs(clip_lib, tmp_path, fixture_cache,
     imgs = fixtures.synthetic_images(2, 32)
     assert np.array_equal(a.image_batch_encode(imgs), b.image_batch_encode(imgs))
     assert not clip_lib.quantize(src, dst, 5)  # invalid itype
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the dev container")
+@pytest.mark.parametrize("prog", ["examples/main.cpp", "examples/zsl.cpp", "examples/extract.cpp", "examples/simple.c",
+                                  "tests/benchmark.cpp", "models/quantize.cpp"])
+def test_reference_programs_build_unchanged_against_this_library(clip_lib, tmp_path, prog):
+    """Drop-in acceptance: the reference's own callers compile and link against include/ + libclip.so with no edits."""
+    libdir = os.path.dirname(clip_lib.LIB_PATH)
+    src = os.path.join(REFERENCE, prog)
+    cmd = (["gcc", "-std=c11"] if prog.endswith(".c") else ["g++", "-std=c++17"]) + ["-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(REFERENCE, "examples"), src]
+    if prog.endswith(".cpp") and "quantize" not in prog:
+        cmd.append(os.path.join(REFERENCE, "examples", "common-clip.cpp"))
+    cmd += ["-L", libdir, "-lclip", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "prog")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
