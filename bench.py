@@ -167,7 +167,7 @@ def main():
         orc = ref.OracleModel(path)
         ns = max(1, args.cpu_sample)
         h_imgs = imgs[:ns].cpu().numpy()
-        cores = os.cpu_count() or 1
+        cores = ref.host_cores()
         t = time.perf_counter()
         want = orc.image_batch_encode(h_imgs, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=cores)
         for ids in texts[:ns]:

@@ -31,6 +31,7 @@ namespace clipamd {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -45,25 +46,25 @@ __device__ __forceinline__ h2 splat(float x) { return (h2){(_Float16)x, (_Float1
 __device__ __forceinline__ int lds_off(int r, int c) { return r * BK + ((c ^ (r & 7)) << 3); }
 
 // ---------------------------------------------------------------------------------------------
-// Raw (still quantised) per-thread slice of the weight tile, and its dequantisation to 4 x uint4
+// Raw (still quantised) per-thread slice of the weight tile, and its dequantisation to 4 x u32x4
 // (= 32 fp16 = one quant block = chunks 0..3 of that block).
 // ---------------------------------------------------------------------------------------------
 template <int WT> struct RawBlock;
 
-template <> struct RawBlock<W_Q4_0> { uint4 qs; half_t d; };
-template <> struct RawBlock<W_Q4_1> { uint4 qs; h2 dm; };
-template <> struct RawBlock<W_Q5_0> { uint4 qs; uint32_t qh; half_t d; };
-template <> struct RawBlock<W_Q5_1> { uint4 qs; uint32_t qh; h2 dm; };
-template <> struct RawBlock<W_Q8_0> { uint4 qs0, qs1; half_t d; };
+template <> struct RawBlock<W_Q4_0> { u32x4 qs; half_t d; };
+template <> struct RawBlock<W_Q4_1> { u32x4 qs; h2 dm; };
+template <> struct RawBlock<W_Q5_0> { u32x4 qs; uint32_t qh; half_t d; };
+template <> struct RawBlock<W_Q5_1> { u32x4 qs; uint32_t qh; h2 dm; };
+template <> struct RawBlock<W_Q8_0> { u32x4 qs0, qs1; half_t d; };
 
 template <int WT>
 __device__ __forceinline__ void load_block(RawBlock<WT> & r, const DevWeight & W, size_t idx) {
     if constexpr (WT == W_Q8_0) {
-        const uint4 * q = (const uint4 *)W.qs + idx * 2;
+        const u32x4 * q = (const u32x4 *)W.qs + idx * 2;
         r.qs0 = q[0];
         r.qs1 = q[1];
     } else {
-        r.qs = ((const uint4 *)W.qs)[idx];
+        r.qs = ((const u32x4 *)W.qs)[idx];
     }
     if constexpr (WT == W_Q5_0 || WT == W_Q5_1) r.qh = ((const uint32_t *)W.qh)[idx];
     if constexpr (WT == W_Q4_1 || WT == W_Q5_1) r.dm = ((const h2 *)W.dm)[idx];
@@ -75,7 +76,8 @@ __device__ __forceinline__ void load_block(RawBlock<WT> & r, const DevWeight & W
 //   ((w >> 4s) & 0x000F000F) = { lo half: element 2s, hi half: element 2s+1 }  (adjacent pair).
 // OR-ing 0x6400 into each half gives the fp16 number 1024+q exactly.
 template <int WT>
-__device__ __forceinline__ void dequant_block(const RawBlock<WT> & r, uint4 (&out)[4]) {
+__device__ __forceinline__ void dequant_block(const RawBlock<WT> & r, u32x4 & out0, u32x4 & out1, u32x4 & out2, u32x4 & out3) {
+    u32x4 out[4];
     if constexpr (WT == W_Q4_0 || WT == W_Q4_1 || WT == W_Q5_0 || WT == W_Q5_1) {
         const uint32_t w[4] = {r.qs.x, r.qs.y, r.qs.z, r.qs.w};
         h2 scale, sub, add;
@@ -100,11 +102,11 @@ __device__ __forceinline__ void dequant_block(const RawBlock<WT> & r, uint4 (&ou
                     u |= hb & M5;
                 }
                 h2 v = u2h(u) - sub;  // exact small integer
-                if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = v * scale + add;
+                if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
                 else v = v * scale;
                 o[s] = h2u(v);
             }
-            out[j] = make_uint4(o[0], o[1], o[2], o[3]);
+            out[j] = (u32x4){o[0], o[1], o[2], o[3]};
         }
     } else if constexpr (WT == W_Q8_0) {
         // bytes are stored as (int8 ^ 0x80) in the order [e0, e2, e1, e3] per 32-bit word, so
@@ -123,10 +125,18 @@ __device__ __forceinline__ void dequant_block(const RawBlock<WT> & r, uint4 (&ou
                 o[2 * t + 0] = h2u((u2h(u0) - sub) * scale);
                 o[2 * t + 1] = h2u((u2h(u1) - sub) * scale);
             }
-            out[j] = make_uint4(o[0], o[1], o[2], o[3]);
+            out[j] = (u32x4){o[0], o[1], o[2], o[3]};
         }
     }
+    out0 = out[0]; out1 = out[1]; out2 = out[2]; out3 = out[3];
 }
+
+// registers of one prefetched tile: X chunks + either f16 weight chunks or one raw quant block
+template <int WT, int BM, int BN> struct TileRegs {
+    u32x4 x[BM * 8 / NTHREADS];
+    u32x4 w16[WT == W_F16 ? BN * 8 / NTHREADS : 1];
+    RawBlock<(WT == W_F16 ? W_Q4_0 : WT)> wq;
+};
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // ggml_gelu_f32: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))
@@ -140,7 +150,7 @@ __device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf
 
 // ---------------------------------------------------------------------------------------------
 template <int WT, int BM, int BN, int EPI>
-__global__ void __launch_bounds__(NTHREADS) gemm_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half_t * Ws = (half_t *)smem_raw;                 // [2][BN*BK]
     half_t * Xs = Ws + 2 * BN * BK;                   // [2][BM*BK]
@@ -149,7 +159,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const GemmParams p) {
     constexpr int TM = BM / 32;
     constexpr int XCH = BM * 8 / NTHREADS;            // 16 B chunks of the X tile per thread
     constexpr int WCH = BN * 8 / NTHREADS;            // (f16 weights) chunks per thread
-    constexpr int WBLK = (BN * 2 + NTHREADS - 1) / NTHREADS;  // (quant) blocks per thread
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,66 +182,50 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const GemmParams p) {
     const int nkb = p.W.Kpad / 32;
     (void)nkb;
 
-    // ---- per-thread global source coordinates ----
-    const half_t * xsrc[XCH];
-    int xdst[XCH];
+    // ---- per-thread global source coordinates (chunk q = tid + i*256 -> row (tid>>3) + 32 i, chunk tid&7) ----
+    const int xrow0 = tid >> 3, xc = tid & 7;
+    const int xlds0 = lds_off(xrow0, xc);     // rows advance by 32 per i: (row & 7) is unchanged -> offset += 32*BK
+    size_t xgoff[XCH];
 #pragma unroll
     for (int i = 0; i < XCH; i++) {
-        const int q = tid + i * NTHREADS;
-        const int row = q >> 3, c = q & 7;
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;  // clamp: rows past M are computed but never stored
-        xsrc[i] = p.A + (size_t)gm * p.lda + c * 8;
-        xdst[i] = lds_off(row, c);
+        int gm = m0 + xrow0 + 32 * i;
+        gm = gm < p.M ? gm : p.M - 1;          // clamp: rows past M are computed but never stored
+        xgoff[i] = (size_t)gm * p.lda + xc * 8;
     }
+    // quantised weights: item = tid + i*256 -> (row item % BN, block item / BN)
+    const int wnl = tid % BN, wkb = tid / BN;  // BN=128: wkb in {0,1}; BN=64: wkb in {0..3} (only < 2 used)
 
-    uint4 xr[XCH];
-    uint4 wr16[WT == W_F16 ? WCH : 1];
-    RawBlock<(WT == W_F16 ? W_Q4_0 : WT)> wrq[WT == W_F16 ? 1 : WBLK];
-
-    auto load_tile = [&](int kt) {
+    TileRegs<WT, BM, BN> R0, R1;
+    auto load_tile = [&](TileRegs<WT, BM, BN> & R, int kt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < XCH; i++) xr[i] = *(const uint4 *)(xsrc[i] + kt * BK);
+        for (int i = 0; i < XCH; i++) R.x[i] = *(const u32x4 *)(p.A + xgoff[i] + kt * BK);
         if constexpr (WT == W_F16) {
 #pragma unroll
-            for (int i = 0; i < WCH; i++) {
-                const int q = tid + i * NTHREADS;
-                const int row = q >> 3, c = q & 7;
-                wr16[i] = *(const uint4 *)((const half_t *)p.W.w16 + (size_t)(n0 + row) * p.W.Kpad + kt * BK + c * 8);
-            }
+            for (int i = 0; i < WCH; i++)
+                R.w16[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + kt * BK + xc * 8);
         } else {
-#pragma unroll
-            for (int i = 0; i < WBLK; i++) {
-                const int item = tid + i * NTHREADS;
-                if (item < BN * 2) {
-                    const int nl = item % BN, kbl = item / BN;
-                    load_block<WT>(wrq[i], p.W, (size_t)(kt * 2 + kbl) * p.W.Npad + n0 + nl);
-                }
-            }
+            if (BN * 2 >= NTHREADS || tid < BN * 2)
+                load_block<WT>(R.wq, p.W, (size_t)(kt * 2 + wkb) * p.W.Npad + n0 + wnl);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const TileRegs<WT, BM, BN> & R, int buf) __attribute__((always_inline)) {
         half_t * xs = Xs + buf * BM * BK;
         half_t * ws = Ws + buf * BN * BK;
 #pragma unroll
-        for (int i = 0; i < XCH; i++) *(uint4 *)(xs + xdst[i]) = xr[i];
+        for (int i = 0; i < XCH; i++) *(u32x4 *)(xs + xlds0 + i * 32 * BK) = R.x[i];
         if constexpr (WT == W_F16) {
 #pragma unroll
-            for (int i = 0; i < WCH; i++) {
-                const int q = tid + i * NTHREADS;
-                *(uint4 *)(ws + lds_off(q >> 3, q & 7)) = wr16[i];
-            }
+            for (int i = 0; i < WCH; i++) *(u32x4 *)(ws + xlds0 + i * 32 * BK) = R.w16[i];
         } else {
-#pragma unroll
-            for (int i = 0; i < WBLK; i++) {
-                const int item = tid + i * NTHREADS;
-                if (item < BN * 2) {
-                    const int nl = item % BN, kbl = item / BN;
-                    uint4 dq[4];
-                    dequant_block<WT>(wrq[i], dq);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) *(uint4 *)(ws + lds_off(nl, kbl * 4 + j)) = dq[j];
-                }
+            if (BN * 2 >= NTHREADS || tid < BN * 2) {
+                u32x4 d0, d1, d2, d3;
+                dequant_block<WT>(R.wq, d0, d1, d2, d3);
+                half_t * wrow = ws + wnl * BK;
+                const int sw = wnl & 7, cb = wkb * 4;
+                *(u32x4 *)(wrow + (((cb + 0) ^ sw) << 3)) = d0;
+                *(u32x4 *)(wrow + (((cb + 1) ^ sw) << 3)) = d1;
+                *(u32x4 *)(wrow + (((cb + 2) ^ sw) << 3)) = d2;
+                *(u32x4 *)(wrow + (((cb + 3) ^ sw) << 3)) = d3;
             }
         }
     };
@@ -243,16 +236,10 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int frow = lane & 15, fgrp = lane >> 4;
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const half_t * xs = Xs + cur * BM * BK;
-        const half_t * ws = Ws + cur * BN * BK;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const half_t * xs = Xs + buf * BM * BK;
+        const half_t * ws = Ws + buf * BN * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             h8 wf[TN], xf[TM];
@@ -272,9 +259,25 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const GemmParams p) {
                 for (int b = 0; b < TM; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+
+    // ---- main loop: two register stages (tiles k+1 and k+2 in flight) + two LDS buffers, one barrier per K-step ----
+    load_tile(R0, 0);
+    if (nk > 1) load_tile(R1, 1);
+    store_tile(R0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        if (kt + 2 < nk) load_tile(R0, kt + 2);
+        compute(0);
+        store_tile(R1, 1);
+        __syncthreads();
+        if (kt + 3 < nk) load_tile(R1, kt + 3);
+        compute(1);
+        if (kt + 2 < nk) store_tile(R0, 0);
         __syncthreads();
     }
+    if (kt < nk) compute(0);   // odd tail (its tile was stored by the last iteration / the prologue)
 
     // ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15)
     const int N = p.W.N;

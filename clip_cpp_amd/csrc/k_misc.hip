@@ -23,8 +23,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (ggml_norm semantics: biased variance, y = (x-mean) * 1/sqrt(var+eps), then *w + b;
 // reference clip.cpp:1350-1355, ggml_compute_forward_norm).  Wave-shuffle reductions only.
 // ---------------------------------------------------------------------------------------------
-constexpr int LN_MAXV = 8;  // float4 per lane -> h <= 2048
-
+// NV = float4 per lane (h <= 256*NV): a template parameter so the row stays in NV*4 registers
+template <int LN_MAXV>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float * __restrict__ x, int ldx, const int * __restrict__ in_rows, int in_row_mul,
                                                         const float * __restrict__ w, const float * __restrict__ b, float eps,
                                                         int rows, int h, half_t * __restrict__ out16, int ld16,
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) l2norm_kernel(const float * __restrict__ v, float * __restrict__ out, int rows, int n,
+__global__ void __launch_bounds__(256, 4) l2norm_kernel(const float * __restrict__ v, float * __restrict__ out, int rows, int n,
                                                      int normalize) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -209,8 +209,15 @@ __global__ void __launch_bounds__(256) f16_to_f32_kernel(const half_t * __restri
 void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_mul, const float * w, const float * b, float eps,
                       int rows, int h, half_t * out16, int ld16, float * out32, int ld32, hipStream_t stream) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, in_rows, in_row_mul, w, b, eps, rows, h,
-                       out16, ld16, out32, ld32);
+    const dim3 grid((rows + 3) / 4), block(256);
+#define CLIPAMD_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, stream, x, ldx, in_rows, in_row_mul, w, b, eps, rows, h, out16, ld16, out32, ld32)
+    if (h <= 256) CLIPAMD_LN(1);
+    else if (h <= 512) CLIPAMD_LN(2);
+    else if (h <= 768) CLIPAMD_LN(3);
+    else if (h <= 1024) CLIPAMD_LN(4);
+    else if (h <= 1280) CLIPAMD_LN(5);
+    else CLIPAMD_LN(8);   // h <= 2048
+#undef CLIPAMD_LN
 }
 
 void launch_im2col(const float * imgs, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream) {

@@ -29,6 +29,34 @@ def build(force=False):
 _lib = None
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container on a
+    256-thread host often owns only a few cores; spawning 256 OpenMP threads there is catastrophically slow)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 32))
+
+
+def _threads(n):
+    return n if n and n > 0 else host_cores()
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -96,7 +124,7 @@ def mul_mat(type_id, raw, N, K, X, mode=MODE_FAITHFUL, n_threads=0):
     X = np.ascontiguousarray(X, dtype=np.float32)
     M = X.shape[0]
     Y = np.empty((M, N), dtype=np.float32)
-    lib().orc_mul_mat(type_id, raw.ctypes.data_as(C.c_void_p), N, K, _fp(X), M, _fp(Y), mode, n_threads)
+    lib().orc_mul_mat(type_id, raw.ctypes.data_as(C.c_void_p), N, K, _fp(X), M, _fp(Y), mode, _threads(n_threads))
     return Y
 
 
@@ -153,18 +181,18 @@ class OracleModel:
             T = (self.info["v_S"] // self.info["v_P"]) ** 2 + 1
             t0 = np.empty((B * T, self.info["v_h"]), dtype=np.float32)
             t1 = np.empty_like(t0)
-            ok = lib().orc_image_batch_encode_taps(self.h, mode, n_threads, _fp(imgs), B, _fp(out), int(normalize),
+            ok = lib().orc_image_batch_encode_taps(self.h, mode, _threads(n_threads), _fp(imgs), B, _fp(out), int(normalize),
                                                    _fp(t0), _fp(t1))
             assert ok
             return out, t0, t1
-        ok = lib().orc_image_batch_encode(self.h, mode, n_threads, _fp(imgs), B, _fp(out), int(normalize))
+        ok = lib().orc_image_batch_encode(self.h, mode, _threads(n_threads), _fp(imgs), B, _fp(out), int(normalize))
         assert ok
         return out
 
     def text_encode(self, ids, normalize=True, mode=MODE_FAITHFUL, n_threads=0):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         out = np.empty(self.info["t_proj"], dtype=np.float32)
-        ok = lib().orc_text_encode(self.h, mode, n_threads, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size,
+        ok = lib().orc_text_encode(self.h, mode, _threads(n_threads), ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size,
                                    _fp(out), int(normalize))
         if not ok:
             raise RuntimeError("oracle text_encode failed")

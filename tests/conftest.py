@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:  # torch must initialise ITS bundled HIP runtime before libclip.so pulls in /opt/rocm's (same soname): the other
+    import torch  # noqa: F401  order leaves torch without a visible GPU in this process
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except Exception:  # torch is optional for everything except the device-pointer test
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
