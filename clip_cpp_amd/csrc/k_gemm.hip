@@ -46,97 +46,75 @@ __device__ __forceinline__ h2 splat(float x) { return (h2){(_Float16)x, (_Float1
 __device__ __forceinline__ int lds_off(int r, int c) { return r * BK + ((c ^ (r & 7)) << 3); }
 
 // ---------------------------------------------------------------------------------------------
-// Raw (still quantised) per-thread slice of the weight tile, and its dequantisation to 4 x u32x4
-// (= 32 fp16 = one quant block = chunks 0..3 of that block).
+// Quantised weights never touch LDS: every wave loads, per 16x32 MFMA A-fragment, ONE 32-bit word of
+// packed quants per lane (plus the block scale) straight from the block-column-major planes and
+// dequantises it in registers into the 8 fp16 values the MFMA wants.
+//
+// Packed nibble layout (load.cpp repack_rows): 32-bit word j of a block holds elements 8j..8j+7;
+// nibble p<4 is element 2p, nibble p>=4 is element 2(p-4)+1.  Hence
+//   ((w >> 4s) & 0x000F000F) = { lo half: element 2s, hi half: element 2s+1 }  (adjacent pair)
+// and OR-ing 0x6400 into each half gives the fp16 number 1024+q exactly.  Lane (row = lane&15,
+// k-group g = lane>>4) of the MFMA A operand owns elements 8g..8g+7 of the block = word g.
+// q5: fifth bits in a parallel word: bit pi = 4j+s -> element 2s of word j, bit 16+pi -> element 2s+1.
+// q8_0: bytes stored as (int8 ^ 0x80) in the order [e0,e2,e1,e3] per word: (w & 0x00FF00FF) = {e0,e1},
+//   ((w >> 8) & 0x00FF00FF) = {e2,e3}; 0x6400|u8 = 1024 + (q+128); lane g owns words 2g, 2g+1.
 // ---------------------------------------------------------------------------------------------
-template <int WT> struct RawBlock;
+template <int WT> struct WFrag;
+template <> struct WFrag<W_F16> { uint32_t q; };   // unused
+template <> struct WFrag<W_Q4_0> { uint32_t q; half_t d; };
+template <> struct WFrag<W_Q4_1> { uint32_t q; h2 dm; };
+template <> struct WFrag<W_Q5_0> { uint32_t q, h; half_t d; };
+template <> struct WFrag<W_Q5_1> { uint32_t q, h; h2 dm; };
+template <> struct WFrag<W_Q8_0> { uint32_t q, q1; half_t d; };
 
-template <> struct RawBlock<W_Q4_0> { u32x4 qs; half_t d; };
-template <> struct RawBlock<W_Q4_1> { u32x4 qs; h2 dm; };
-template <> struct RawBlock<W_Q5_0> { u32x4 qs; uint32_t qh; half_t d; };
-template <> struct RawBlock<W_Q5_1> { u32x4 qs; uint32_t qh; h2 dm; };
-template <> struct RawBlock<W_Q8_0> { u32x4 qs0, qs1; half_t d; };
-
+// idx = kb * Npad + n (block index in the planes), g = lane >> 4
 template <int WT>
-__device__ __forceinline__ void load_block(RawBlock<WT> & r, const DevWeight & W, size_t idx) {
+__device__ __forceinline__ void load_wfrag(WFrag<WT> & f, const DevWeight & W, size_t idx, int g) {
     if constexpr (WT == W_Q8_0) {
-        const u32x4 * q = (const u32x4 *)W.qs + idx * 2;
-        r.qs0 = q[0];
-        r.qs1 = q[1];
+        const uint2 v = *(const uint2 *)((const uint8_t *)W.qs + idx * 32 + g * 8);
+        f.q = v.x;
+        f.q1 = v.y;
     } else {
-        r.qs = ((const u32x4 *)W.qs)[idx];
+        f.q = *(const uint32_t *)((const uint8_t *)W.qs + idx * 16 + g * 4);
     }
-    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) r.qh = ((const uint32_t *)W.qh)[idx];
-    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) r.dm = ((const h2 *)W.dm)[idx];
-    else r.d = ((const half_t *)W.dm)[idx];
+    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) f.h = ((const uint32_t *)W.qh)[idx];
+    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) f.dm = ((const h2 *)W.dm)[idx];
+    else f.d = ((const half_t *)W.dm)[idx];
 }
 
-// Packed nibble layout (model.cpp repack_q4/q5): 32-bit word j of qs holds elements 8j..8j+7 of the
-// block; nibble p<4 is element 2p, nibble p>=4 is element 2(p-4)+1.  Hence
-//   ((w >> 4s) & 0x000F000F) = { lo half: element 2s, hi half: element 2s+1 }  (adjacent pair).
-// OR-ing 0x6400 into each half gives the fp16 number 1024+q exactly.
 template <int WT>
-__device__ __forceinline__ void dequant_block(const RawBlock<WT> & r, u32x4 & out0, u32x4 & out1, u32x4 & out2, u32x4 & out3) {
-    u32x4 out[4];
-    if constexpr (WT == W_Q4_0 || WT == W_Q4_1 || WT == W_Q5_0 || WT == W_Q5_1) {
-        const uint32_t w[4] = {r.qs.x, r.qs.y, r.qs.z, r.qs.w};
+__device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
+    uint32_t o[4];
+    if constexpr (WT == W_Q8_0) {
+        const h2 scale = (h2){f.d, f.d};
+        const h2 sub = splat(1152.0f);
+        o[0] = h2u((u2h((f.q & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
+        o[1] = h2u((u2h(((f.q >> 8) & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
+        o[2] = h2u((u2h((f.q1 & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
+        o[3] = h2u((u2h(((f.q1 >> 8) & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
+    } else {
         h2 scale, sub, add;
-        if constexpr (WT == W_Q4_0) { scale = (h2){r.d, r.d}; sub = splat(1032.0f); }
-        if constexpr (WT == W_Q5_0) { scale = (h2){r.d, r.d}; sub = splat(1040.0f); }
+        if constexpr (WT == W_Q4_0) { scale = (h2){f.d, f.d}; sub = splat(1032.0f); }
+        if constexpr (WT == W_Q5_0) { scale = (h2){f.d, f.d}; sub = splat(1040.0f); }
         if constexpr (WT == W_Q4_1 || WT == W_Q5_1) {
-            scale = (h2){r.dm[0], r.dm[0]};
-            add = (h2){r.dm[1], r.dm[1]};
+            scale = (h2){f.dm[0], f.dm[0]};
+            add = (h2){f.dm[1], f.dm[1]};
             sub = splat(1024.0f);
         }
+        uint32_t hb = 0;
+        if constexpr (WT == W_Q5_0 || WT == W_Q5_1) hb = (uint32_t)(((uint64_t)f.h << 4) >> (4 * g));  // pair bits of word g at 4+s / 20+s
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t o[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                uint32_t u = ((w[j] >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
-                if constexpr (WT == W_Q5_0 || WT == W_Q5_1) {
-                    // fifth bits: pair index pi = 4j+s; bit pi -> element 2s, bit 16+pi -> element 2s+1
-                    constexpr uint32_t M5 = 0x00100010u;
-                    const int pi = 4 * j + s;
-                    const uint32_t hb = (pi >= 4) ? (r.qh >> (pi - 4)) : (r.qh << (4 - pi));
-                    u |= hb & M5;
-                }
-                h2 v = u2h(u) - sub;  // exact small integer
-                if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
-                else v = v * scale;
-                o[s] = h2u(v);
-            }
-            out[j] = (u32x4){o[0], o[1], o[2], o[3]};
-        }
-    } else if constexpr (WT == W_Q8_0) {
-        // bytes are stored as (int8 ^ 0x80) in the order [e0, e2, e1, e3] per 32-bit word, so
-        //   (w & 0x00FF00FF) = {e0, e1},  ((w >> 8) & 0x00FF00FF) = {e2, e3}; 0x6400|u8 = 1024 + (q+128).
-        const uint32_t w[8] = {r.qs0.x, r.qs0.y, r.qs0.z, r.qs0.w, r.qs1.x, r.qs1.y, r.qs1.z, r.qs1.w};
-        const h2 scale = (h2){r.d, r.d};
-        const h2 sub = splat(1152.0f);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t o[4];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const uint32_t ww = w[2 * j + t];
-                const uint32_t u0 = (ww & 0x00FF00FFu) | 0x64006400u;
-                const uint32_t u1 = ((ww >> 8) & 0x00FF00FFu) | 0x64006400u;
-                o[2 * t + 0] = h2u((u2h(u0) - sub) * scale);
-                o[2 * t + 1] = h2u((u2h(u1) - sub) * scale);
-            }
-            out[j] = (u32x4){o[0], o[1], o[2], o[3]};
+        for (int s = 0; s < 4; s++) {
+            uint32_t u = ((f.q >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
+            if constexpr (WT == W_Q5_0 || WT == W_Q5_1) u |= (hb >> s) & 0x00100010u;
+            h2 v = u2h(u) - sub;  // exact small integer
+            if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
+            else v = v * scale;
+            o[s] = h2u(v);
         }
     }
-    out0 = out[0]; out1 = out[1]; out2 = out[2]; out3 = out[3];
+    return __builtin_bit_cast(h8, (u32x4){o[0], o[1], o[2], o[3]});
 }
-
-// registers of one prefetched tile: X chunks + either f16 weight chunks or one raw quant block
-template <int WT, int BM, int BN> struct TileRegs {
-    u32x4 x[BM * 8 / NTHREADS];
-    u32x4 w16[WT == W_F16 ? BN * 8 / NTHREADS : 1];
-    RawBlock<(WT == W_F16 ? W_Q4_0 : WT)> wq;
-};
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // ggml_gelu_f32: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))
@@ -151,9 +129,10 @@ __device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf
 // ---------------------------------------------------------------------------------------------
 template <int WT, int BM, int BN, int EPI>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
+    constexpr bool WLDS = (WT == W_F16);              // f16 weights are staged through LDS like X; quantised ones are not
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    half_t * Ws = (half_t *)smem_raw;                 // [2][BN*BK]
-    half_t * Xs = Ws + 2 * BN * BK;                   // [2][BM*BK]
+    half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
+    half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]   (f16 weights only)
 
     constexpr int TN = BN / 32;   // 16-row MFMA fragments per wave along N (wave owns BN/2 rows)
     constexpr int TM = BM / 32;
@@ -164,6 +143,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
 
     // ---- XCD-aware tile mapping (bijective for any grid size) ----
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -177,10 +157,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
     }
     const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-
     const int nk = p.W.Kpad / BK;
-    const int nkb = p.W.Kpad / 32;
-    (void)nkb;
 
     // ---- per-thread global source coordinates (chunk q = tid + i*256 -> row (tid>>3) + 32 i, chunk tid&7) ----
     const int xrow0 = tid >> 3, xc = tid & 7;
@@ -192,43 +169,25 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
         gm = gm < p.M ? gm : p.M - 1;          // clamp: rows past M are computed but never stored
         xgoff[i] = (size_t)gm * p.lda + xc * 8;
     }
-    // quantised weights: item = tid + i*256 -> (row item % BN, block item / BN)
-    const int wnl = tid % BN, wkb = tid / BN;  // BN=128: wkb in {0,1}; BN=64: wkb in {0..3} (only < 2 used)
+    const int wrow = n0 + wn * (BN / 2) + frow;   // this lane's weight row of fragment 0 (quantised path)
 
-    TileRegs<WT, BM, BN> R0, R1;
-    auto load_tile = [&](TileRegs<WT, BM, BN> & R, int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < XCH; i++) R.x[i] = *(const u32x4 *)(p.A + xgoff[i] + kt * BK);
-        if constexpr (WT == W_F16) {
-#pragma unroll
-            for (int i = 0; i < WCH; i++)
-                R.w16[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + kt * BK + xc * 8);
-        } else {
-            if (BN * 2 >= NTHREADS || tid < BN * 2)
-                load_block<WT>(R.wq, p.W, (size_t)(kt * 2 + wkb) * p.W.Npad + n0 + wnl);
-        }
-    };
-    auto store_tile = [&](const TileRegs<WT, BM, BN> & R, int buf) __attribute__((always_inline)) {
-        half_t * xs = Xs + buf * BM * BK;
-        half_t * ws = Ws + buf * BN * BK;
-#pragma unroll
-        for (int i = 0; i < XCH; i++) *(u32x4 *)(xs + xlds0 + i * 32 * BK) = R.x[i];
-        if constexpr (WT == W_F16) {
-#pragma unroll
-            for (int i = 0; i < WCH; i++) *(u32x4 *)(ws + xlds0 + i * 32 * BK) = R.w16[i];
-        } else {
-            if (BN * 2 >= NTHREADS || tid < BN * 2) {
-                u32x4 d0, d1, d2, d3;
-                dequant_block<WT>(R.wq, d0, d1, d2, d3);
-                half_t * wrow = ws + wnl * BK;
-                const int sw = wnl & 7, cb = wkb * 4;
-                *(u32x4 *)(wrow + (((cb + 0) ^ sw) << 3)) = d0;
-                *(u32x4 *)(wrow + (((cb + 1) ^ sw) << 3)) = d1;
-                *(u32x4 *)(wrow + (((cb + 2) ^ sw) << 3)) = d2;
-                *(u32x4 *)(wrow + (((cb + 3) ^ sw) << 3)) = d3;
-            }
-        }
-    };
+    u32x4 X0[XCH], X1[XCH];                   // two register stages of the X tile
+    u32x4 W0[WLDS ? WCH : 1], W1[WLDS ? WCH : 1];
+    WFrag<WT> F0[WLDS ? 1 : TN * 2], F1[WLDS ? 1 : TN * 2];   // two stages of raw weight fragments [a][kk]
+
+#define LOAD_X(R, kt_)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < XCH; i++) R[i] = *(const u32x4 *)(p.A + xgoff[i] + (kt_) * BK);
+#define STORE_X(R, buf_)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < XCH; i++) *(u32x4 *)(Xs + (buf_) * BM * BK + xlds0 + i * 32 * BK) = R[i];
+#define LOAD_W16(R, kt_)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < WCH; i++)                                            \
+        R[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + (kt_) * BK + xc * 8);
+#define STORE_W16(R, buf_)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < WCH; i++) *(u32x4 *)(Ws + (buf_) * BN * BK + xlds0 + i * 32 * BK) = R[i];
+#define LOAD_WQ(F, kt_)                                                                        \
+    _Pragma("unroll") for (int a = 0; a < TN; a++)                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                       \
+            load_wfrag<WT>(F[a * 2 + kk], p.W, (size_t)((kt_) * 2 + kk) * p.W.Npad + wrow + a * 16, fgrp);
 
     f4 acc[TN][TM];
 #pragma unroll
@@ -236,48 +195,68 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fgrp = lane >> 4;
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-        const half_t * xs = Xs + buf * BM * BK;
-        const half_t * ws = Ws + buf * BN * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            h8 wf[TN], xf[TM];
-#pragma unroll
-            for (int a = 0; a < TN; a++) {
-                const int row = wn * (BN / 2) + a * 16 + frow;
-                wf[a] = *(const h8 *)(ws + lds_off(row, kk * 4 + fgrp));
-            }
-#pragma unroll
-            for (int b = 0; b < TM; b++) {
-                const int row = wm * (BM / 2) + b * 16 + frow;
-                xf[b] = *(const h8 *)(xs + lds_off(row, kk * 4 + fgrp));
-            }
-#pragma unroll
-            for (int a = 0; a < TN; a++)
-#pragma unroll
-                for (int b = 0; b < TM; b++)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
-        }
-    };
+#define COMPUTE(buf_, F)                                                                       \
+    {                                                                                          \
+        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
+        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
+        (void)ws;                                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
+            h8 xf[TM];                                                                         \
+            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
+                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
+            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
+                h8 wf;                                                                         \
+                if constexpr (WLDS) wf = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
+                else wf = dequant_wfrag<WT>(F[a * 2 + kk], fgrp);                              \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
+            }                                                                                  \
+        }                                                                                      \
+    }
 
-    // ---- main loop: two register stages (tiles k+1 and k+2 in flight) + two LDS buffers, one barrier per K-step ----
-    load_tile(R0, 0);
-    if (nk > 1) load_tile(R1, 1);
-    store_tile(R0, 0);
+    // ---- main loop.  X (and f16 W): two register stages (tiles k+1, k+2 in flight) + two LDS buffers.
+    //      Quantised W: fragments of tile k+1 are loaded into registers while tile k is multiplied. One barrier per K-step.
+    LOAD_X(X0, 0);
+    if constexpr (WLDS) { LOAD_W16(W0, 0); } else { LOAD_WQ(F0, 0); }
+    if (nk > 1) {
+        LOAD_X(X1, 1);
+        if constexpr (WLDS) { LOAD_W16(W1, 1); }
+    }
+    STORE_X(X0, 0);
+    if constexpr (WLDS) { STORE_W16(W0, 0); }
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        if (kt + 2 < nk) load_tile(R0, kt + 2);
-        compute(0);
-        store_tile(R1, 1);
+        if (kt + 2 < nk) {
+            LOAD_X(X0, kt + 2);
+            if constexpr (WLDS) { LOAD_W16(W0, kt + 2); }
+        }
+        if constexpr (!WLDS) { LOAD_WQ(F1, kt + 1); }
+        COMPUTE(0, F0);
+        STORE_X(X1, 1);
+        if constexpr (WLDS) { STORE_W16(W1, 1); }
         __syncthreads();
-        if (kt + 3 < nk) load_tile(R1, kt + 3);
-        compute(1);
-        if (kt + 2 < nk) store_tile(R0, 0);
+        if (kt + 3 < nk) {
+            LOAD_X(X1, kt + 3);
+            if constexpr (WLDS) { LOAD_W16(W1, kt + 3); }
+        }
+        if constexpr (!WLDS) {
+            if (kt + 2 < nk) { LOAD_WQ(F0, kt + 2); }
+        }
+        COMPUTE(1, F1);
+        if (kt + 2 < nk) {
+            STORE_X(X0, 0);
+            if constexpr (WLDS) { STORE_W16(W0, 0); }
+        }
         __syncthreads();
     }
-    if (kt < nk) compute(0);   // odd tail (its tile was stored by the last iteration / the prologue)
+    if (kt < nk) COMPUTE(0, F0);   // odd tail (its X tile was stored by the last iteration / the prologue)
+#undef LOAD_X
+#undef STORE_X
+#undef LOAD_W16
+#undef STORE_W16
+#undef LOAD_WQ
+#undef COMPUTE
 
     // ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15)
     const int N = p.W.N;
@@ -322,7 +301,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
 template <int WT, int BM, int BN, int EPI>
 void launch_one(const GemmParams & p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
-    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    const size_t smem = (size_t)2 * (BM + (WT == W_F16 ? BN : 0)) * BK * sizeof(half_t);
     hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
 }
 
