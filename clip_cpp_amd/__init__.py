@@ -62,7 +62,7 @@ AMD_SYMBOLS = [
     "clip_amd_device_count", "clip_amd_model_load", "clip_amd_ctx_device", "clip_amd_set_stream",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
-    "clip_amd_test_gemm", "clip_amd_test_layernorm", "clip_amd_test_attention",
+    "clip_amd_test_gemm", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def lib():
     L.clip_amd_profile_report.argtypes = [vp, C.c_char_p, i32, C.c_bool]
     L.clip_amd_test_gemm.restype = i32
     L.clip_amd_test_gemm.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32]
+    L.clip_amd_bench_gemm.restype = C.c_float
+    L.clip_amd_bench_gemm.argtypes = [i32, C.c_int64, C.c_int64, C.c_int64, i32, i32, i32]
     L.clip_amd_test_layernorm.restype = i32
     L.clip_amd_test_layernorm.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int64, C.c_int64, f32p, i32]
     L.clip_amd_test_attention.restype = i32

@@ -462,6 +462,45 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
     return rc;
 }
 
+
+// Micro-benchmark of one GEMM shape through the production kernel (random weights of ggml type `type`,
+// quantised with the product codecs).  Returns the average kernel time in microseconds (HIP events), < 0 on error.
+float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return -1.f; }
+    std::vector<float> w((size_t)N * K);
+    uint32_t st = 12345u;
+    for (auto & v : w) { st = st * 1664525u + 1013904223u; v = ((int)(st >> 9) % 2001 - 1000) * 4e-5f; }
+    std::vector<uint8_t> raw(ggml_row_bytes(type, K) * (size_t)N);
+    if (raw.empty() || quantize_rows(type, w.data(), raw.data(), N, K) == 0) return -2.f;
+    DevWeight W;
+    void * wbase = nullptr;
+    if (!repack_for_test(type, raw.data(), N, K, W, &wbase)) return -2.f;
+    const int Kpad = W.Kpad;
+    DBuf dx((size_t)(M + 1) * Kpad * 2), dbias((size_t)N * 4), dout((size_t)M * N * 4);
+    std::vector<uint16_t> hx((size_t)M * Kpad);
+    for (auto & v : hx) { st = st * 1664525u + 1013904223u; v = f32_to_f16_bits(((int)(st >> 9) % 2001 - 1000) * 1e-3f); }
+    (void)hipMemcpy(dx.p, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemset(dbias.p, 0, (size_t)N * 4);
+    (void)hipMemset(dout.p, 0, (size_t)M * N * 4);
+    GemmParams p;
+    p.A = (const half_t *)dx.p; p.lda = Kpad; p.M = (int)M; p.W = W; p.bias = (const float *)dbias.p; p.ldc = (int)N; p.out = dout.p;
+    p.resid = (const float *)dout.p; p.qcols = 0;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    for (int i = 0; i < 3; i++) launch_gemm(p, epilogue, tile, nullptr);
+    (void)hipEventRecord(a, nullptr);
+    for (int i = 0; i < iters; i++) launch_gemm(p, epilogue, tile, nullptr);
+    (void)hipEventRecord(b, nullptr);
+    float ms = -1.f;
+    if (hipEventSynchronize(b) == hipSuccess && hipGetLastError() == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(wbase);
+    return ms < 0 ? -4.f : ms * 1000.f / iters;
+}
+
 int clip_amd_test_layernorm(const float * x, const float * w, const float * b, float eps, int64_t rows, int64_t h, float * y, int out_f16) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return -1; }

@@ -84,7 +84,9 @@ __device__ __forceinline__ void load_wfrag(WFrag<WT> & f, const DevWeight & W, s
 
 template <int WT>
 __device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
-    uint32_t o[4];
+    uint32_t o[4] = {0, 0, 0, 0};
+    if constexpr (WT == W_F16) return __builtin_bit_cast(h8, (u32x4){f.q, 0u, 0u, 0u});
+    else
     if constexpr (WT == W_Q8_0) {
         const h2 scale = (h2){f.d, f.d};
         const h2 sub = splat(1152.0f);
@@ -116,6 +118,40 @@ __device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
     return __builtin_bit_cast(h8, (u32x4){o[0], o[1], o[2], o[3]});
 }
 
+// One whole 32-weight block per thread (LDS-staged path): the 4 (q8_0: 8) packed words + fifth bits + scale.
+template <int WT> struct RawBlock { u32x4 qs, qs1; uint32_t h; half_t d; h2 dm; };
+
+template <int WT>
+__device__ __forceinline__ void load_block(RawBlock<WT> & r, const DevWeight & W, size_t idx) {
+    if constexpr (WT == W_Q8_0) {
+        const u32x4 * q = (const u32x4 *)W.qs + idx * 2;
+        r.qs = q[0];
+        r.qs1 = q[1];
+    } else if constexpr (WT != W_F16) {
+        r.qs = ((const u32x4 *)W.qs)[idx];
+    }
+    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) r.h = ((const uint32_t *)W.qh)[idx];
+    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) r.dm = ((const h2 *)W.dm)[idx];
+    else if constexpr (WT != W_F16) r.d = ((const half_t *)W.dm)[idx];
+}
+
+// word j (8 weights) of a block as a register fragment
+template <int WT>
+__device__ __forceinline__ WFrag<WT> block_word(const RawBlock<WT> & r, int j) {
+    WFrag<WT> f;
+    if constexpr (WT == W_Q8_0) {
+        const uint32_t w[8] = {r.qs[0], r.qs[1], r.qs[2], r.qs[3], r.qs1[0], r.qs1[1], r.qs1[2], r.qs1[3]};
+        f.q = w[2 * j];
+        f.q1 = w[2 * j + 1];
+    } else {
+        f.q = r.qs[j];
+    }
+    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) f.h = r.h;
+    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) f.dm = r.dm;
+    else if constexpr (WT != W_F16) f.d = r.d;
+    return f;
+}
+
 __device__ __forceinline__ float gelu_tanh(float x) {
     // ggml_gelu_f32: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))
     const float u = 0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x);
@@ -127,9 +163,12 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 __device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 // ---------------------------------------------------------------------------------------------
-template <int WT, int BM, int BN, int EPI>
+template <int WT, int BM, int BN, int EPI, bool DIRECT>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
-    constexpr bool WLDS = (WT == W_F16);              // f16 weights are staged through LDS like X; quantised ones are not
+    // WLDS: the weight tile is staged (dequantised) through LDS like X.  !WLDS (DIRECT, quantised types only): every wave
+    // loads its own MFMA A-fragments as packed quants straight into registers and dequantises beside the MFMAs.
+    constexpr bool WLDS = (WT == W_F16) || !DIRECT;
+    constexpr bool WQLDS = WLDS && (WT != W_F16);     // quantised weights through LDS: one 32-weight block per thread per K-step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
     half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]   (f16 weights only)
@@ -172,18 +211,33 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
     const int wrow = n0 + wn * (BN / 2) + frow;   // this lane's weight row of fragment 0 (quantised path)
 
     u32x4 X0[XCH], X1[XCH];                   // two register stages of the X tile
-    u32x4 W0[WLDS ? WCH : 1], W1[WLDS ? WCH : 1];
-    WFrag<WT> F0[WLDS ? 1 : TN * 2], F1[WLDS ? 1 : TN * 2];   // two stages of raw weight fragments [a][kk]
+    u32x4 W0[WT == W_F16 ? WCH : 1], W1[WT == W_F16 ? WCH : 1];
+    WFrag<WT> F0[WLDS ? 1 : TN * 2], F1[WLDS ? 1 : TN * 2];   // DIRECT: two stages of raw weight fragments [a][kk]
+    RawBlock<WT> B0, B1;                                      // WQLDS: two stages of one raw block per thread
+    const int bnl = tid % BN, bkb = tid / BN;                 // block (row bnl, k-block bkb) of the tile handled by this thread
+    const bool bact = (BN * 2 >= NTHREADS) || tid < BN * 2;
 
 #define LOAD_X(R, kt_)                                                                         \
     _Pragma("unroll") for (int i = 0; i < XCH; i++) R[i] = *(const u32x4 *)(p.A + xgoff[i] + (kt_) * BK);
 #define STORE_X(R, buf_)                                                                       \
     _Pragma("unroll") for (int i = 0; i < XCH; i++) *(u32x4 *)(Xs + (buf_) * BM * BK + xlds0 + i * 32 * BK) = R[i];
-#define LOAD_W16(R, kt_)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < WCH; i++)                                            \
-        R[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + (kt_) * BK + xc * 8);
-#define STORE_W16(R, buf_)                                                                     \
-    _Pragma("unroll") for (int i = 0; i < WCH; i++) *(u32x4 *)(Ws + (buf_) * BN * BK + xlds0 + i * 32 * BK) = R[i];
+#define LOAD_W16(R, B, kt_)                                                                    \
+    if constexpr (WT == W_F16) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < WCH; i++)                                        \
+            R[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + (kt_) * BK + xc * 8); \
+    } else {                                                                                   \
+        if (bact) load_block<WT>(B, p.W, (size_t)((kt_) * 2 + bkb) * p.W.Npad + n0 + bnl);     \
+    }
+#define STORE_W16(R, B, buf_)                                                                  \
+    if constexpr (WT == W_F16) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < WCH; i++) *(u32x4 *)(Ws + (buf_) * BN * BK + xlds0 + i * 32 * BK) = R[i]; \
+    } else {                                                                                   \
+        if (bact) {                                                                            \
+            half_t * wrow_ = Ws + (buf_) * BN * BK + bnl * BK;                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; j++)                                      \
+                *(h8 *)(wrow_ + (((bkb * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(B, j), j); \
+        }                                                                                      \
+    }
 #define LOAD_WQ(F, kt_)                                                                        \
     _Pragma("unroll") for (int a = 0; a < TN; a++)                                             \
         _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                       \
@@ -217,28 +271,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
     // ---- main loop.  X (and f16 W): two register stages (tiles k+1, k+2 in flight) + two LDS buffers.
     //      Quantised W: fragments of tile k+1 are loaded into registers while tile k is multiplied. One barrier per K-step.
     LOAD_X(X0, 0);
-    if constexpr (WLDS) { LOAD_W16(W0, 0); } else { LOAD_WQ(F0, 0); }
+    if constexpr (WLDS) { LOAD_W16(W0, B0, 0); } else { LOAD_WQ(F0, 0); }
     if (nk > 1) {
         LOAD_X(X1, 1);
-        if constexpr (WLDS) { LOAD_W16(W1, 1); }
+        if constexpr (WLDS) { LOAD_W16(W1, B1, 1); }
     }
     STORE_X(X0, 0);
-    if constexpr (WLDS) { STORE_W16(W0, 0); }
+    if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         if (kt + 2 < nk) {
             LOAD_X(X0, kt + 2);
-            if constexpr (WLDS) { LOAD_W16(W0, kt + 2); }
+            if constexpr (WLDS) { LOAD_W16(W0, B0, kt + 2); }
         }
         if constexpr (!WLDS) { LOAD_WQ(F1, kt + 1); }
         COMPUTE(0, F0);
         STORE_X(X1, 1);
-        if constexpr (WLDS) { STORE_W16(W1, 1); }
+        if constexpr (WLDS) { STORE_W16(W1, B1, 1); }
         __syncthreads();
         if (kt + 3 < nk) {
             LOAD_X(X1, kt + 3);
-            if constexpr (WLDS) { LOAD_W16(W1, kt + 3); }
+            if constexpr (WLDS) { LOAD_W16(W1, B1, kt + 3); }
         }
         if constexpr (!WLDS) {
             if (kt + 2 < nk) { LOAD_WQ(F0, kt + 2); }
@@ -246,7 +300,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
         COMPUTE(1, F1);
         if (kt + 2 < nk) {
             STORE_X(X0, 0);
-            if constexpr (WLDS) { STORE_W16(W0, 0); }
+            if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
         }
         __syncthreads();
     }
@@ -298,20 +352,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
     }
 }
 
-template <int WT, int BM, int BN, int EPI>
+template <int WT, int BM, int BN, int EPI, bool DIRECT>
 void launch_one(const GemmParams & p, hipStream_t stream) {
+    constexpr bool WLDS = (WT == W_F16) || !DIRECT;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
-    const size_t smem = (size_t)2 * (BM + (WT == W_F16 ? BN : 0)) * BK * sizeof(half_t);
-    hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
+    const size_t smem = (size_t)2 * (BM + (WLDS ? BN : 0)) * BK * sizeof(half_t);
+    hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, EPI, DIRECT>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
 }
 
+// tile code: variant * 1000000 + BM * 1000 + BN; variant 0 = weights staged through LDS, 1 = per-wave register fragments
 template <int WT, int EPI>
 void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
-    switch (tile) {
-    case 128128: launch_one<WT, 128, 128, EPI>(p, stream); break;
-    case 64128: launch_one<WT, 64, 128, EPI>(p, stream); break;
-    case 128064: launch_one<WT, 128, 64, EPI>(p, stream); break;
-    default: launch_one<WT, 64, 64, EPI>(p, stream); break;
+    const bool direct = (tile / 1000000) == 1 && WT != W_F16;
+    switch (tile % 1000000) {
+    case 128128: direct ? launch_one<WT, 128, 128, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 128, 128, EPI, false>(p, stream); break;
+    case 64128: direct ? launch_one<WT, 64, 128, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 64, 128, EPI, false>(p, stream); break;
+    case 128064: direct ? launch_one<WT, 128, 64, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 128, 64, EPI, false>(p, stream); break;
+    default: direct ? launch_one<WT, 64, 64, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 64, 64, EPI, false>(p, stream); break;
     }
 }
 

@@ -65,6 +65,9 @@ int clip_amd_profile_report(struct clip_ctx * ctx, char * buf, int cap, bool res
  *           4 residual: Y = resid + X.W^T + bias (f32).  tile: 0 auto, else BM*1000+BN. */
 int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M,
                        const float * bias, const float * resid, float * y, int epilogue, int tile);
+/* Average device time (microseconds, HIP events) of one GEMM shape through the production kernel on random
+ * weights of ggml type `type`; < 0 on error.  Used by scripts/gemm_bench.py for kernel A/B work. */
+float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters);
 /* y = LayerNorm(x)*w + b, rows x h. out_f16 != 0 rounds the result through fp16. */
 int clip_amd_test_layernorm(const float * x, const float * w, const float * b, float eps, int64_t rows, int64_t h,
                             float * y, int out_f16);

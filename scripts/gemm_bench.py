@@ -1,0 +1,31 @@
+"""GEMM micro-benchmark over shapes / tiles (kernel A/B work).  usage: python scripts/gemm_bench.py [tile ...]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+try:
+    import torch  # noqa: F401  (HIP runtime order, see tests/conftest.py)
+except Exception:
+    pass
+import clip_cpp_amd  # noqa: E402
+
+L = clip_cpp_amd.lib()
+TYPES = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}
+SHAPES = [  # (name, M, N, K, epi)
+    ("b32.qkv", 12800, 2304, 768, 1), ("b32.out", 12800, 768, 768, 4), ("b32.up", 12800, 3072, 768, 3), ("b32.down", 12800, 768, 3072, 4),
+    ("b32.b32.up", 1600, 3072, 768, 3), ("b32.b32.down", 1600, 768, 3072, 4),
+    ("l14.up", 65792, 4096, 1024, 3), ("l14.down", 65792, 1024, 4096, 4),
+]
+tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
+types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
+only = [a for a in sys.argv[1:] if "." in a]
+for tname in types:
+    for name, M, N, K, epi in SHAPES:
+        if only and name not in only:
+            continue
+        row = []
+        for tile in tiles:
+            us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi, tile, 20)
+            row.append("%7d: %8.1f us %7.1f TF" % (tile, us, 2.0 * M * N * K / us / 1e6 if us > 0 else -1))
+        print("%-5s %-14s M=%6d N=%5d K=%5d | %s" % (tname, name, M, N, K, " | ".join(row)), flush=True)
