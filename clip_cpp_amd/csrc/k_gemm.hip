@@ -162,6 +162,174 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 __device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
+// ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15).
+// nbase / mbase: first weight row / activation row of this wave's sub-tile.
+template <int EPI, int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp) {
+    const int N = p.W.N;
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        const int n = nbase + a * 16 + fgrp * 4;
+        if (n >= N) continue;
+        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_PATCH_F32 && p.bias) bias = *(const f4 *)(p.bias + n);
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            const int m = mbase + b * 16 + frow;
+            if (m >= p.M) continue;
+            f4 v = acc[a][b] + bias;
+            if constexpr (EPI == EPI_F32) {
+                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                const f4 r = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
+                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r + v;
+            } else if constexpr (EPI == EPI_PATCH_F32) {
+                const int img = m / p.Np, pp = m % p.Np;
+                const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
+                *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
+            } else {
+                if constexpr (EPI == EPI_F16) {
+                    if (n < p.qcols) v = v * p.qscale;
+                } else if constexpr (EPI == EPI_GELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
+                } else if constexpr (EPI == EPI_QGELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
+                }
+                const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
+                const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
+                *(uint2 *)((half_t *)p.out + (size_t)m * p.ldc + n) = make_uint2(h2u(lo), h2u(hi));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised variant: 512 threads = 4 COMPUTE waves (ds_read + MFMA only, 2x2 over the BMxBN tile) and
+// 4 LOADER waves (global loads two K-steps ahead, dequantisation, ds_write), one of each kind per SIMD, so the
+// matrix pipe keeps running while the next tile is fetched / dequantised / staged.  Two LDS buffers, one
+// workgroup barrier per K-step: after it the compute waves read the buffer the loaders just filled and the
+// loaders overwrite the one the compute waves just finished with.
+// ---------------------------------------------------------------------------------------------
+template <int WT, int BM, int BN, int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
+    half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]
+    constexpr int TN = BN / 32, TM = BM / 32;
+    constexpr int XCH = BM * 8 / NTHREADS, WCH = BN * 8 / NTHREADS;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.W.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.W.Kpad / BK;
+    const int last = nk - 1;
+
+    if (wave >= 4) {
+        // ================================ LOADER waves ================================
+        const int lt = tid - 256;
+        const int xrow0 = lt >> 3, xc = lt & 7;
+        const int xlds0 = lds_off(xrow0, xc);
+        size_t xgoff[XCH];
+#pragma unroll
+        for (int i = 0; i < XCH; i++) {
+            int gm = m0 + xrow0 + 32 * i;
+            gm = gm < p.M ? gm : p.M - 1;
+            xgoff[i] = (size_t)gm * p.lda + xc * 8;
+        }
+        const int bnl = lt % BN, bkb = lt / BN;
+        const bool bact = (BN * 2 >= NTHREADS) || lt < BN * 2;
+        u32x4 X0[XCH], X1[XCH];
+        u32x4 W0[WT == W_F16 ? WCH : 1], W1[WT == W_F16 ? WCH : 1];
+        RawBlock<WT> B0, B1;
+#define WS_LOAD(XR, WR, BR, kt_)                                                               \
+        {                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < XCH; i++) XR[i] = *(const u32x4 *)(p.A + xgoff[i] + (kt_) * BK); \
+            if constexpr (WT == W_F16) {                                                       \
+                _Pragma("unroll") for (int i = 0; i < WCH; i++)                                \
+                    WR[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + (kt_) * BK + xc * 8); \
+            } else {                                                                           \
+                if (bact) load_block<WT>(BR, p.W, (size_t)((kt_) * 2 + bkb) * p.W.Npad + n0 + bnl); \
+            }                                                                                  \
+        }
+#define WS_STORE(XR, WR, BR, buf_)                                                             \
+        {                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < XCH; i++) *(u32x4 *)(Xs + (buf_) * BM * BK + xlds0 + i * 32 * BK) = XR[i]; \
+            if constexpr (WT == W_F16) {                                                       \
+                _Pragma("unroll") for (int i = 0; i < WCH; i++) *(u32x4 *)(Ws + (buf_) * BN * BK + xlds0 + i * 32 * BK) = WR[i]; \
+            } else {                                                                           \
+                if (bact) {                                                                    \
+                    half_t * wrow_ = Ws + (buf_) * BN * BK + bnl * BK;                         \
+                    _Pragma("unroll") for (int j = 0; j < 4; j++)                              \
+                        *(h8 *)(wrow_ + (((bkb * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(BR, j), j); \
+                }                                                                              \
+            }                                                                                  \
+        }
+        WS_LOAD(X0, W0, B0, 0);
+        { const int t1 = last < 1 ? last : 1; WS_LOAD(X1, W1, B1, t1); }
+        WS_STORE(X0, W0, B0, 0);
+        __syncthreads();                                   // tile 0 visible
+        for (int kt = 0; kt < nk; kt += 2) {
+            { const int t2 = kt + 2 < last ? kt + 2 : last; WS_LOAD(X0, W0, B0, t2); }
+            WS_STORE(X1, W1, B1, 1);                       // tile kt+1 -> buf1 (compute is on buf0)
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            { const int t3 = kt + 3 < last ? kt + 3 : last; WS_LOAD(X1, W1, B1, t3); }
+            WS_STORE(X0, W0, B0, 0);                       // tile kt+2 -> buf0 (compute is on buf1)
+            __syncthreads();
+        }
+#undef WS_LOAD
+#undef WS_STORE
+    } else {
+    // ================================ COMPUTE waves ================================
+    const int lane = tid & 63;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+#define WS_COMPUTE(buf_)                                                                       \
+    {                                                                                          \
+        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
+        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
+            h8 xf[TM];                                                                         \
+            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
+                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
+            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
+                const h8 wf = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
+            }                                                                                  \
+        }                                                                                      \
+    }
+    __syncthreads();                                       // tile 0 visible
+    for (int kt = 0; kt < nk; kt += 2) {
+        WS_COMPUTE(0);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        WS_COMPUTE(1);
+        __syncthreads();
+    }
+#undef WS_COMPUTE
+    asm volatile("" ::: "memory");   // keep the epilogue's bias / residual loads below the main loop (register pressure)
+    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int WT, int BM, int BN, int EPI, bool DIRECT>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
@@ -194,7 +362,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
+    // n fastest: the tiles_n workgroups that share one X row-panel run back to back on one XCD, so the panel is
+    // fetched into that L2 once; the (small) weight matrix stays L2-resident anyway.
+    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = p.W.Kpad / BK;
 
@@ -270,38 +440,41 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
 
     // ---- main loop.  X (and f16 W): two register stages (tiles k+1, k+2 in flight) + two LDS buffers.
     //      Quantised W: fragments of tile k+1 are loaded into registers while tile k is multiplied. One barrier per K-step.
+    // Every prefetch is UNCONDITIONAL (tile index clamped to the last tile): a load inside an `if` makes hipcc's
+    // s_waitcnt insertion assume it may not have been issued and fall back to vmcnt(0/1) for the older tile, which
+    // exposes the full memory latency of the tile just requested on every K-step.
+    const int last = nk - 1;
     LOAD_X(X0, 0);
     if constexpr (WLDS) { LOAD_W16(W0, B0, 0); } else { LOAD_WQ(F0, 0); }
-    if (nk > 1) {
-        LOAD_X(X1, 1);
-        if constexpr (WLDS) { LOAD_W16(W1, B1, 1); }
+    {
+        const int t1 = last < 1 ? last : 1;
+        LOAD_X(X1, t1);
+        if constexpr (WLDS) { LOAD_W16(W1, B1, t1); }
     }
     STORE_X(X0, 0);
     if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        if (kt + 2 < nk) {
-            LOAD_X(X0, kt + 2);
-            if constexpr (WLDS) { LOAD_W16(W0, B0, kt + 2); }
+        {
+            const int t2 = kt + 2 < last ? kt + 2 : last;
+            LOAD_X(X0, t2);
+            if constexpr (WLDS) { LOAD_W16(W0, B0, t2); }
+            if constexpr (!WLDS) { LOAD_WQ(F1, kt + 1); }
         }
-        if constexpr (!WLDS) { LOAD_WQ(F1, kt + 1); }
         COMPUTE(0, F0);
         STORE_X(X1, 1);
         if constexpr (WLDS) { STORE_W16(W1, B1, 1); }
         __syncthreads();
-        if (kt + 3 < nk) {
-            LOAD_X(X1, kt + 3);
-            if constexpr (WLDS) { LOAD_W16(W1, B1, kt + 3); }
-        }
-        if constexpr (!WLDS) {
-            if (kt + 2 < nk) { LOAD_WQ(F0, kt + 2); }
+        {
+            const int t3 = kt + 3 < last ? kt + 3 : last;
+            LOAD_X(X1, t3);
+            if constexpr (WLDS) { LOAD_W16(W1, B1, t3); }
+            if constexpr (!WLDS) { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_WQ(F0, t2); }
         }
         COMPUTE(1, F1);
-        if (kt + 2 < nk) {
-            STORE_X(X0, 0);
-            if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
-        }
+        STORE_X(X0, 0);
+        if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
         __syncthreads();
     }
     if (kt < nk) COMPUTE(0, F0);   // odd tail (its X tile was stored by the last iteration / the prologue)
@@ -312,44 +485,143 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
 #undef LOAD_WQ
 #undef COMPUTE
 
-    // ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15)
-    const int N = p.W.N;
-#pragma unroll
-    for (int a = 0; a < TN; a++) {
-        const int n = n0 + wn * (BN / 2) + a * 16 + fgrp * 4;
-        if (n >= N) continue;
-        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PATCH_F32 && p.bias) bias = *(const f4 *)(p.bias + n);
-#pragma unroll
-        for (int b = 0; b < TM; b++) {
-            const int m = m0 + wm * (BM / 2) + b * 16 + frow;
-            if (m >= p.M) continue;
-            f4 v = acc[a][b] + bias;
-            if constexpr (EPI == EPI_F32) {
-                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                const f4 r = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
-                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r + v;
-            } else if constexpr (EPI == EPI_PATCH_F32) {
-                const int img = m / p.Np, pp = m % p.Np;
-                const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
-                *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
-            } else {
-                if constexpr (EPI == EPI_F16) {
-                    if (n < p.qcols) v = v * p.qscale;
-                } else if constexpr (EPI == EPI_GELU_F16) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
-                } else if constexpr (EPI == EPI_QGELU_F16) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
-                }
-                const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
-                const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
-                *(uint2 *)((half_t *)p.out + (size_t)m * p.ldc + n) = make_uint2(h2u(lo), h2u(hi));
-            }
-        }
+    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: fp16 tiles (X always, W when the weights are f16) go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write): one wave-instruction moves a 1 KB piece = 8 tile rows;
+// the LDS image is lane-linear, so the 16-byte-chunk XOR swizzle is applied on the per-lane SOURCE address
+// (lane l writes row l>>3, position l&7, and therefore fetches chunk (l&7)^(l>>3)); fragment reads use lds_off().
+// Quantised weights: one raw 32-weight block per thread in registers (two stages), dequantised into LDS.
+// Per K-step: issue DMA for tile k+1 + register loads for tile k+2, multiply tile k, dequant-store tile k+1, barrier
+// (the barrier's vmcnt(0) is what lands the DMA, so nothing inside a step waits on memory).
+// ---------------------------------------------------------------------------------------------
+template <int WT, int BM, int BN, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
+    half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]
+    constexpr int TN = BN / 32, TM = BM / 32;
+    constexpr int XPW = BM / 32;                      // 1 KB pieces of the X tile per wave
+    constexpr int WPW = BN / 32;                      // (f16 weights) pieces of the W tile per wave
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.W.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.W.Kpad / BK;
+    const int last = nk - 1;
+
+    // DMA source addresses: piece = wave*XPW + i covers tile rows piece*8 .. +7
+    const int prow = lane >> 3;
+    const int pchunk = (lane & 7) ^ prow;
+    const half_t * xsrc[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; i++) {
+        int gm = m0 + (wave * XPW + i) * 8 + prow;
+        gm = gm < p.M ? gm : p.M - 1;
+        xsrc[i] = p.A + (size_t)gm * p.lda + pchunk * 8;
+    }
+    const half_t * wsrc[WT == W_F16 ? WPW : 1];
+    if constexpr (WT == W_F16) {
+#pragma unroll
+        for (int i = 0; i < WPW; i++)
+            wsrc[i] = (const half_t *)p.W.w16 + (size_t)(n0 + (wave * WPW + i) * 8 + prow) * p.W.Kpad + pchunk * 8;
+    }
+    RawBlock<WT> B0, B1;
+    const int bnl = tid % BN, bkb = tid / BN;
+    const bool bact = (BN * 2 >= NTHREADS) || tid < BN * 2;
+
+#define DMA_TILE(buf_, kt_)                                                                    \
+    {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < XPW; i++)                                        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[i] + (kt_) * BK), \
+                (__attribute__((address_space(3))) void *)(Xs + (buf_) * BM * BK + (wave * XPW + i) * 512), 16, 0, 0); \
+        if constexpr (WT == W_F16) {                                                           \
+            _Pragma("unroll") for (int i = 0; i < WPW; i++)                                    \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[i] + (kt_) * BK), \
+                    (__attribute__((address_space(3))) void *)(Ws + (buf_) * BN * BK + (wave * WPW + i) * 512), 16, 0, 0); \
+        }                                                                                      \
+    }
+#define LOAD_B(B, kt_)                                                                         \
+    if constexpr (WT != W_F16) {                                                               \
+        if (bact) load_block<WT>(B, p.W, (size_t)((kt_) * 2 + bkb) * p.W.Npad + n0 + bnl);     \
+    }
+#define STORE_B(B, buf_)                                                                       \
+    if constexpr (WT != W_F16) {                                                               \
+        if (bact) {                                                                            \
+            half_t * wrow_ = Ws + (buf_) * BN * BK + bnl * BK;                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; j++)                                      \
+                *(h8 *)(wrow_ + (((bkb * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(B, j), j); \
+        }                                                                                      \
+    }
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+#define COMPUTE(buf_)                                                                          \
+    {                                                                                          \
+        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
+        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
+            h8 xf[TM];                                                                         \
+            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
+                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
+            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
+                const h8 wf = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
+            }                                                                                  \
+        }                                                                                      \
+    }
+
+    DMA_TILE(0, 0);
+    LOAD_B(B0, 0);
+    { const int t1 = last < 1 ? last : 1; LOAD_B(B1, t1); }
+    STORE_B(B0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        DMA_TILE(1, kt + 1);
+        { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
+        COMPUTE(0);
+        STORE_B(B1, 1);
+        __syncthreads();
+        { const int t2 = kt + 2 < last ? kt + 2 : last; DMA_TILE(0, t2); }
+        { const int t3 = kt + 3 < last ? kt + 3 : last; LOAD_B(B1, t3); }
+        COMPUTE(1);
+        STORE_B(B0, 0);
+        __syncthreads();
+    }
+    if (kt < nk) COMPUTE(0);
+#undef DMA_TILE
+#undef LOAD_B
+#undef STORE_B
+#undef COMPUTE
+    asm volatile("" ::: "memory");
+    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
+}
+
+template <int WT, int BM, int BN, int EPI>
+void launch_dma(const GemmParams & p, hipStream_t stream) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
+    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
 }
 
 template <int WT, int BM, int BN, int EPI, bool DIRECT>
@@ -361,8 +633,31 @@ void launch_one(const GemmParams & p, hipStream_t stream) {
 }
 
 // tile code: variant * 1000000 + BM * 1000 + BN; variant 0 = weights staged through LDS, 1 = per-wave register fragments
+template <int WT, int BM, int BN, int EPI>
+void launch_ws(const GemmParams & p, hipStream_t stream) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
+    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    hipLaunchKernelGGL((gemm_ws_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(512), smem, stream, p);
+}
+
 template <int WT, int EPI>
 void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
+    if (tile / 1000000 == 3) {   // LDS-DMA staging
+        switch (tile % 1000000) {
+        case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;
+        case 128064: launch_dma<WT, 128, 64, EPI>(p, stream); break;
+        case 64064: launch_dma<WT, 64, 64, EPI>(p, stream); break;
+        default: launch_dma<WT, 128, 128, EPI>(p, stream); break;
+        }
+        return;
+    }
+    if (tile / 1000000 == 2) {   // wave-specialised
+        switch (tile % 1000000) {
+        case 64128: launch_ws<WT, 64, 128, EPI>(p, stream); break;
+        default: launch_ws<WT, 128, 128, EPI>(p, stream); break;
+        }
+        return;
+    }
     const bool direct = (tile / 1000000) == 1 && WT != W_F16;
     switch (tile % 1000000) {
     case 128128: direct ? launch_one<WT, 128, 128, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 128, 128, EPI, false>(p, stream); break;
