@@ -486,6 +486,8 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     GemmParams p;
     p.A = (const half_t *)dx.p; p.lda = Kpad; p.M = (int)M; p.W = W; p.bias = (const float *)dbias.p; p.ldc = (int)N; p.out = dout.p;
     p.resid = (const float *)dout.p; p.qcols = 0;
+    p.debug = epilogue >> 8;   // ablation switches in the high bits (tuning only)
+    epilogue &= 0xFF;
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);

@@ -596,6 +596,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
     STORE_B(B0, 0);
     __syncthreads();
     int kt = 0;
+    if (p.debug == 0) {
     for (; kt + 1 < nk; kt += 2) {
         DMA_TILE(1, kt + 1);
         { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
@@ -607,6 +608,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
         COMPUTE(1);
         STORE_B(B0, 0);
         __syncthreads();
+    }
+    } else {   // ablation copy of the loop (kernel tuning only; results are garbage)
+    const bool noload = p.debug & 1, nomfma = p.debug & 2, nostore = p.debug & 4;
+    for (; kt + 1 < nk; kt += 2) {
+        if (!noload) { DMA_TILE(1, kt + 1); const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
+        if (!nomfma) COMPUTE(0);
+        if (!nostore) { STORE_B(B1, 1); }
+        __syncthreads();
+        if (!noload) { const int t2 = kt + 2 < last ? kt + 2 : last; DMA_TILE(0, t2); const int t3 = kt + 3 < last ? kt + 3 : last; LOAD_B(B1, t3); }
+        if (!nomfma) COMPUTE(1);
+        if (!nostore) { STORE_B(B0, 0); }
+        __syncthreads();
+    }
     }
     if (kt < nk) COMPUTE(0);
 #undef DMA_TILE
@@ -622,6 +636,189 @@ void launch_dma(const GemmParams & p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
     const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
     hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ring variant (3-slot LDS ring, everything staged by LDS-DMA, two tiles in flight, ONE raw barrier per K-step):
+//   * X tile (and the W tile of f16 weights): global_load_lds_dwordx4, swizzled via the source address as above;
+//   * quantised W tile: the RAW packed blocks are DMA'd (16 B quants + 2/4 B scale (+4 B fifth bits) per block) —
+//     4.5-8.5 bits per weight also inside LDS — and dequantised in registers when a wave builds its MFMA
+//     A-fragment (ds_read_b32 of word g + ds_read_u16 of the scale -> 8 fp16).  No dequantised copy is ever written.
+//   * no VGPR-destination global load exists in the loop, so the waits are hand-counted: after multiplying tile k
+//     a wave waits `vmcnt(NI)` (= its own NI DMA instructions of tile k+2 may stay in flight, those of tile k+1
+//     have landed), then s_barrier publishes every wave's part of tile k+1 and retires slot k%3 for reuse.
+// BN is fixed at 128: each of the 4 waves DMAs exactly one 64-block piece of quants/scales per tile.
+// ---------------------------------------------------------------------------------------------
+template <int WT> struct RingFmt { static constexpr int QB = 16, DB = 2, HB = 0; };
+template <> struct RingFmt<W_Q4_1> { static constexpr int QB = 16, DB = 4, HB = 0; };
+template <> struct RingFmt<W_Q5_0> { static constexpr int QB = 16, DB = 2, HB = 4; };
+template <> struct RingFmt<W_Q5_1> { static constexpr int QB = 16, DB = 4, HB = 4; };
+template <> struct RingFmt<W_Q8_0> { static constexpr int QB = 32, DB = 2, HB = 0; };
+
+#define CLIPAMD_GLDS(gptr_, lptr_, size_) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_), (__attribute__((address_space(3))) void *)(lptr_), size_, 0, 0)
+
+template <int WT, int BM, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_ring_kernel(const GemmParams p) {
+    constexpr int BN = 128;
+    constexpr bool WF16 = (WT == W_F16);
+    using RF = RingFmt<WT>;
+    constexpr int NSLOT = 3;
+    constexpr int XS_BYTES = BM * BK * 2;                                   // one X slot
+    constexpr int WS_BYTES = WF16 ? BN * BK * 2 : 2 * BN * (RF::QB + RF::DB + RF::HB);   // one W slot
+    constexpr int Q_OFF = 0, D_OFF = 2 * BN * RF::QB, H_OFF = D_OFF + 2 * BN * RF::DB;  // planes inside a raw W slot
+    constexpr int TN = BN / 32, TM = BM / 32;
+    constexpr int XPW = BM / 32;                                            // X pieces (1 KB) per wave
+    constexpr int WPW = BN / 32;                                            // f16 W pieces per wave
+    // DMA instructions one wave issues per tile (hand-counted for s_waitcnt vmcnt)
+    constexpr int NI = XPW + (WF16 ? WPW : (RF::QB / 16) + 1 + (RF::HB ? 1 : 0));
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char * Xring = smem_raw;
+    unsigned char * Wring = smem_raw + NSLOT * XS_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.W.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.W.Kpad / BK;
+    const int last = nk - 1;
+
+    // ---- DMA sources ----
+    const int prow = lane >> 3;
+    const int pchunk = (lane & 7) ^ prow;
+    const half_t * xsrc[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; i++) {
+        int gm = m0 + (wave * XPW + i) * 8 + prow;
+        gm = gm < p.M ? gm : p.M - 1;
+        xsrc[i] = p.A + (size_t)gm * p.lda + pchunk * 8;
+    }
+    const half_t * wsrc[WF16 ? WPW : 1];
+    if constexpr (WF16) {
+#pragma unroll
+        for (int i = 0; i < WPW; i++)
+            wsrc[i] = (const half_t *)p.W.w16 + (size_t)(n0 + (wave * WPW + i) * 8 + prow) * p.W.Kpad + pchunk * 8;
+    }
+    // quantised: wave w owns the 64-block piece (k-block w>>1, rows (w&1)*64 .. +63); lane l its block
+    const int pkb = wave >> 1;
+    const size_t pblk = (size_t)n0 + (wave & 1) * 64 + lane;     // + (kt*2+pkb)*Npad at issue time
+    const int praw = (pkb * BN + (wave & 1) * 64) ;              // first block index of the piece inside a slot plane
+
+#define RING_DMA(slot_, kt_)                                                                   \
+    {                                                                                          \
+        unsigned char * xs_ = Xring + (slot_) * XS_BYTES;                                      \
+        unsigned char * ws_ = Wring + (slot_) * WS_BYTES;                                      \
+        _Pragma("unroll") for (int i = 0; i < XPW; i++)                                        \
+            CLIPAMD_GLDS(xsrc[i] + (kt_) * BK, xs_ + (wave * XPW + i) * 1024, 16);             \
+        if constexpr (WF16) {                                                                  \
+            _Pragma("unroll") for (int i = 0; i < WPW; i++)                                    \
+                CLIPAMD_GLDS(wsrc[i] + (kt_) * BK, ws_ + (wave * WPW + i) * 1024, 16);         \
+        } else {                                                                               \
+            const size_t bi_ = (size_t)((kt_) * 2 + pkb) * p.W.Npad + pblk;                    \
+            if constexpr (RF::QB == 32) {                                                      \
+                CLIPAMD_GLDS((const uint8_t *)p.W.qs + bi_ * 32, ws_ + Q_OFF + praw * 16, 16);            \
+                CLIPAMD_GLDS((const uint8_t *)p.W.qs + bi_ * 32 + 16, ws_ + Q_OFF + 2 * BN * 16 + praw * 16, 16); \
+            } else {                                                                           \
+                CLIPAMD_GLDS((const uint8_t *)p.W.qs + bi_ * 16, ws_ + Q_OFF + praw * 16, 16); \
+            }                                                                                  \
+            if constexpr (RF::DB == 2) { CLIPAMD_GLDS((const uint8_t *)p.W.dm + bi_ * 2, ws_ + D_OFF + praw * 2, 2); } \
+            else { CLIPAMD_GLDS((const uint8_t *)p.W.dm + bi_ * 4, ws_ + D_OFF + praw * 4, 4); } \
+            if constexpr (RF::HB != 0) { CLIPAMD_GLDS((const uint8_t *)p.W.qh + bi_ * 4, ws_ + H_OFF + praw * 4, 4); } \
+        }                                                                                      \
+    }
+
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+#define RING_COMPUTE(slot_)                                                                    \
+    {                                                                                          \
+        const half_t * xs = (const half_t *)(Xring + (slot_) * XS_BYTES);                      \
+        const unsigned char * ws = Wring + (slot_) * WS_BYTES;                                 \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
+            h8 xf[TM];                                                                         \
+            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
+                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
+            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
+                h8 wf;                                                                         \
+                if constexpr (WF16) {                                                          \
+                    wf = *(const h8 *)((const half_t *)ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
+                } else {                                                                       \
+                    const int blk_ = kk * BN + wn * (BN / 2) + a * 16 + frow;                  \
+                    WFrag<WT> f_;                                                              \
+                    if constexpr (RF::QB == 32) {                                              \
+                        const uint2 q2_ = *(const uint2 *)(ws + Q_OFF + (fgrp >> 1) * (2 * BN * 16) + blk_ * 16 + (fgrp & 1) * 8); \
+                        f_.q = q2_.x; f_.q1 = q2_.y;                                           \
+                    } else {                                                                   \
+                        f_.q = *(const uint32_t *)(ws + Q_OFF + blk_ * 16 + fgrp * 4);         \
+                    }                                                                          \
+                    if constexpr (RF::HB != 0) f_.h = *(const uint32_t *)(ws + H_OFF + blk_ * 4); \
+                    if constexpr (RF::DB == 4) f_.dm = *(const h2 *)(ws + D_OFF + blk_ * 4);   \
+                    else f_.d = *(const half_t *)(ws + D_OFF + blk_ * 2);                      \
+                    wf = dequant_wfrag<WT>(f_, fgrp);                                          \
+                }                                                                              \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
+            }                                                                                  \
+        }                                                                                      \
+    }
+// "my DMA of the older tile has landed" (NI newer instructions may remain in flight), then publish / retire via barrier
+#define RING_SYNC(n_)                                                                          \
+    {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                              \
+        __builtin_amdgcn_s_barrier();                                                          \
+        asm volatile("" ::: "memory");                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+
+    RING_DMA(0, 0);
+    { const int t1 = last < 1 ? last : 1; RING_DMA(1, t1); }
+    RING_SYNC(NI);                                   // tile 0 landed everywhere
+    int slot = 0;                                    // slot of tile kt; tile kt+2 goes to slot+2 (mod 3)
+    for (int kt = 0; kt < nk; kt++) {
+        const int t2 = kt + 2 < last ? kt + 2 : last;
+        const int s2 = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3
+        RING_DMA(s2, t2);
+        RING_COMPUTE(slot);
+        RING_SYNC(NI);                               // tile kt+1 landed everywhere; slot `slot` free again
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the redundant tail prefetches before LDS is released
+#undef RING_DMA
+#undef RING_COMPUTE
+#undef RING_SYNC
+    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
+}
+
+template <int WT, int BM, int EPI>
+void launch_ring(const GemmParams & p, hipStream_t stream) {
+    constexpr int BN = 128;
+    using RF = RingFmt<WT>;
+    constexpr size_t smem = 3 * ((size_t)BM * BK * 2 + (WT == W_F16 ? (size_t)BN * BK * 2 : (size_t)2 * BN * (RF::QB + RF::DB + RF::HB)));
+    static bool attr_set = false;
+    if (smem > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<WT, BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_ring_kernel<WT, BM, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
 }
 
 template <int WT, int BM, int BN, int EPI, bool DIRECT>
@@ -642,6 +839,13 @@ void launch_ws(const GemmParams & p, hipStream_t stream) {
 
 template <int WT, int EPI>
 void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
+    if (tile / 1000000 == 4) {   // 3-slot LDS-DMA ring
+        switch (tile % 1000000) {
+        case 64128: launch_ring<WT, 64, EPI>(p, stream); break;
+        default: launch_ring<WT, 128, EPI>(p, stream); break;
+        }
+        return;
+    }
     if (tile / 1000000 == 3) {   // LDS-DMA staging
         switch (tile % 1000000) {
         case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;

@@ -55,6 +55,7 @@ struct GemmParams {
     int qcols = 0;
     int Np = 0, T = 0;
     const float * pos = nullptr;
+    int debug = 0;   // ablation switches for kernel tuning (scripts/gemm_bench.py): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
 };
 
 // tile: 0 = heuristic, else BM*1000 + BN with BM,BN in {64,128}

@@ -20,12 +20,14 @@ SHAPES = [  # (name, M, N, K, epi)
 tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
 types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
 only = [a for a in sys.argv[1:] if "." in a]
+debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]
 for tname in types:
     for name, M, N, K, epi in SHAPES:
         if only and name not in only:
             continue
         row = []
         for tile in tiles:
-            us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi, tile, 20)
-            row.append("%7d: %8.1f us %7.1f TF" % (tile, us, 2.0 * M * N * K / us / 1e6 if us > 0 else -1))
+            for dbg in debug:
+                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8), tile, 20)
+                row.append("%7d%s: %8.1f us %7.1f TF" % (tile, ("/d%d" % dbg) if dbg else "", us, 2.0 * M * N * K / us / 1e6 if us > 0 else -1))
         print("%-5s %-14s M=%6d N=%5d K=%5d | %s" % (tname, name, M, N, K, " | ".join(row)), flush=True)
