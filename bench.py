@@ -144,22 +144,36 @@ def main():
         torch.cuda.synchronize()
         rep = clip.profile_report(reset=True)
         clip.profile(False)
-        gem = {k: v for k, v in rep.items() if k.startswith("gemm")}
-        if gem:
-            dom = max(gem, key=lambda k: gem[k]["ms"])
-            d = gem[dom]
+        # aggregate by kernel instantiation (= rocprofv3 kernel name), the roofline is quoted for the one with most time
+        inst = {}
+        for k, v in rep.items():
+            if not k.startswith("gemm"):
+                continue
+            name = k.split("/")[0]
+            a = inst.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, shapes=set()))
+            a["ms"] += v["ms"]; a["launches"] += v["launches"]; a["flops"] += v["flops"]; a["bytes"] += v["bytes"]
+            a["shapes"].add(k.split(":")[1])
+        if inst:
+            dom = max(inst, key=lambda k: inst[k]["ms"])
+            d = inst[dom]
             avg_ms = d["ms"] / d["launches"]
-            fl = d["flops"] / d["launches"]
-            achieved = fl / (avg_ms * 1e-3) / 1e12
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in rep.values())
-            roofline = {"bound": "mfma", "kernel": "gemm_kernel (dequant+MFMA fp16) " + dom, "achieved": round(achieved, 2),
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc (scripts/gpu_pmc.sh)
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom)
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "mfma", "kernel": dom + " (dequant + fp16 MFMA GEMM; WT,BM,BN,EPI)", "achieved": round(achieved, 2),
                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4),
-                        "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
-                        "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                        "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
+                        "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
+                        "algorithmic_flops_per_launch": d["flops"] / d["launches"], "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                        "shapes_MxNxK": sorted(d["shapes"]), "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
             kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None}
-                       for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+                       for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:14]}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and N == 1:

@@ -66,9 +66,17 @@ double weight_bytes(const DevWeight & W) {
 }
 
 void gemm(clip_ctx * ctx, const char * what, const GemmParams & p, int epi) {
+    if (!ctx->profiling) {
+        launch_gemm(p, epi, 0, ctx->stream);
+        return;
+    }
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double by = weight_bytes(p.W) + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : 4);
-    ProfScope ps(ctx, what, p.M, p.W.N, p.W.K, fl, by);
+    // tag = kernel instantiation (matches the rocprofv3 kernel name gemm_dma_kernel<WT, BM, BN, EPI>) + role
+    const int tile = gemm_tile_for(p.M, p.W.N);
+    char fam[96];
+    snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", p.W.wtype, tile / 1000, tile % 1000, epi, what);
+    ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
     launch_gemm(p, epi, 0, ctx->stream);
 }
 

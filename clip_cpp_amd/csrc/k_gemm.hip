@@ -8,21 +8,27 @@
 // :1079-1095,1112,1127,1136,1160 (text), plus ggml_conv_2d at :1309.
 //
 // Design (MI355X-first, not a port of ggml's vec_dot kernels):
-//   * block-quantised weights stay quantised in HBM; each workgroup streams the [BN rows x 2 blocks]
-//     slab of its tile with one coalesced 16 B load per lane (block-column-major planes, kernels.h),
-//     dequantises in registers with packed-fp16 VALU (magic-number 0x6400|q trick, v_pk_add/v_pk_mul)
-//     and stages the fp16 tile in LDS;
-//   * activations are fp16 (the producing kernel's epilogue rounded them once), staged through LDS;
-//   * both LDS tiles are [rows][64] fp16 with a 16-byte-chunk XOR swizzle (chunk ^= row & 7) so the
-//     ds_read_b128 fragment reads of v_mfma_f32_16x16x32_f16 are bank-conflict free;
+//   * block-quantised weights stay quantised in HBM (4.5-8.5 bits per weight); a workgroup streams the
+//     [BN rows x 2 blocks] slab of its tile with one coalesced 16 B load per lane (block-column-major planes,
+//     kernels.h), dequantises it in registers with packed-fp16 VALU (magic-number 0x6400|q trick: and-or,
+//     v_pk_add, v_pk_mul / v_pk_fma) and stages the fp16 tile in LDS (two register stages: the block of tile k+2
+//     is in flight while tile k is multiplied and tile k+1 is dequantised);
+//   * fp16 tiles (activations always, weights of f16 files) go L2 -> LDS by LDS-DMA (global_load_lds_dwordx4):
+//     no VGPR round trip, no ds_write; the 16-byte-chunk XOR swizzle (chunk ^= row & 7, conflict-free ds_read_b128
+//     fragment reads) is applied on the per-lane SOURCE address because the DMA image is lane-linear;
 //   * 256 threads = 4 waves in a 2x2 grid; each wave owns a (BN/2)x(BM/2) sub-tile as 16x16 MFMA
-//     fragments, fp32 accumulation; the weight is the MFMA "A" operand so that each lane ends up with
-//     4 consecutive output columns of one row -> 8/16-byte epilogue stores;
-//   * register-prefetch double buffering: tile k+1 is loaded (quantised) into VGPRs before the MFMAs of
-//     tile k are issued, dequantised + written to the other LDS buffer afterwards, one barrier per step;
-//   * workgroup -> tile mapping is XCD-aware (blocks that share a weight slab land on the same L2).
+//     fragments (v_mfma_f32_16x16x32_f16), fp32 accumulation in k order (deterministic); the weight is the MFMA
+//     "A" operand so that each lane ends up with 4 consecutive output columns of one row -> 8/16-byte stores;
+//   * two LDS buffers, one barrier per K-step; the barrier's vmcnt(0) is what lands the DMA, so nothing inside a
+//     K-step waits on memory; every prefetch is unconditional (clamped tile index) so hipcc's s_waitcnt counting
+//     stays exact;
+//   * workgroup -> tile mapping: XCD-contiguous chunks, n fastest, so the workgroups that share an activation
+//     row-panel run back to back on one XCD/L2 (measured: L2 hit rate 32 % -> 85 %, HBM traffic = algorithmic).
 //
 // Roofline: compute (MFMA fp16, 2.5 PFLOP/s dense) for M >= ~256; HBM (weight bytes) for M <= 64.
+// Measured (r01, MI355X): 550-700 TFLOP/s on the ViT-B/32 / L/14 shapes; ablation (profiles/): the ds_read+MFMA
+// loop alone sustains ~1.08 PFLOP/s and the staging alone ~0.9 PFLOP/s-equivalent: the 2-barrier 128^2 structure
+// is the limit, the next step is a 256-wide 8-wave multi-phase pipeline.
 
 #include "kernels.h"
 
@@ -66,21 +72,6 @@ template <> struct WFrag<W_Q4_1> { uint32_t q; h2 dm; };
 template <> struct WFrag<W_Q5_0> { uint32_t q, h; half_t d; };
 template <> struct WFrag<W_Q5_1> { uint32_t q, h; h2 dm; };
 template <> struct WFrag<W_Q8_0> { uint32_t q, q1; half_t d; };
-
-// idx = kb * Npad + n (block index in the planes), g = lane >> 4
-template <int WT>
-__device__ __forceinline__ void load_wfrag(WFrag<WT> & f, const DevWeight & W, size_t idx, int g) {
-    if constexpr (WT == W_Q8_0) {
-        const uint2 v = *(const uint2 *)((const uint8_t *)W.qs + idx * 32 + g * 8);
-        f.q = v.x;
-        f.q1 = v.y;
-    } else {
-        f.q = *(const uint32_t *)((const uint8_t *)W.qs + idx * 16 + g * 4);
-    }
-    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) f.h = ((const uint32_t *)W.qh)[idx];
-    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) f.dm = ((const h2 *)W.dm)[idx];
-    else f.d = ((const half_t *)W.dm)[idx];
-}
 
 template <int WT>
 __device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
@@ -203,289 +194,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
             }
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Wave-specialised variant: 512 threads = 4 COMPUTE waves (ds_read + MFMA only, 2x2 over the BMxBN tile) and
-// 4 LOADER waves (global loads two K-steps ahead, dequantisation, ds_write), one of each kind per SIMD, so the
-// matrix pipe keeps running while the next tile is fetched / dequantised / staged.  Two LDS buffers, one
-// workgroup barrier per K-step: after it the compute waves read the buffer the loaders just filled and the
-// loaders overwrite the one the compute waves just finished with.
-// ---------------------------------------------------------------------------------------------
-template <int WT, int BM, int BN, int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_ws_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
-    half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]
-    constexpr int TN = BN / 32, TM = BM / 32;
-    constexpr int XCH = BM * 8 / NTHREADS, WCH = BN * 8 / NTHREADS;
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int tiles_n = (p.W.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.W.Kpad / BK;
-    const int last = nk - 1;
-
-    if (wave >= 4) {
-        // ================================ LOADER waves ================================
-        const int lt = tid - 256;
-        const int xrow0 = lt >> 3, xc = lt & 7;
-        const int xlds0 = lds_off(xrow0, xc);
-        size_t xgoff[XCH];
-#pragma unroll
-        for (int i = 0; i < XCH; i++) {
-            int gm = m0 + xrow0 + 32 * i;
-            gm = gm < p.M ? gm : p.M - 1;
-            xgoff[i] = (size_t)gm * p.lda + xc * 8;
-        }
-        const int bnl = lt % BN, bkb = lt / BN;
-        const bool bact = (BN * 2 >= NTHREADS) || lt < BN * 2;
-        u32x4 X0[XCH], X1[XCH];
-        u32x4 W0[WT == W_F16 ? WCH : 1], W1[WT == W_F16 ? WCH : 1];
-        RawBlock<WT> B0, B1;
-#define WS_LOAD(XR, WR, BR, kt_)                                                               \
-        {                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < XCH; i++) XR[i] = *(const u32x4 *)(p.A + xgoff[i] + (kt_) * BK); \
-            if constexpr (WT == W_F16) {                                                       \
-                _Pragma("unroll") for (int i = 0; i < WCH; i++)                                \
-                    WR[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + (kt_) * BK + xc * 8); \
-            } else {                                                                           \
-                if (bact) load_block<WT>(BR, p.W, (size_t)((kt_) * 2 + bkb) * p.W.Npad + n0 + bnl); \
-            }                                                                                  \
-        }
-#define WS_STORE(XR, WR, BR, buf_)                                                             \
-        {                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < XCH; i++) *(u32x4 *)(Xs + (buf_) * BM * BK + xlds0 + i * 32 * BK) = XR[i]; \
-            if constexpr (WT == W_F16) {                                                       \
-                _Pragma("unroll") for (int i = 0; i < WCH; i++) *(u32x4 *)(Ws + (buf_) * BN * BK + xlds0 + i * 32 * BK) = WR[i]; \
-            } else {                                                                           \
-                if (bact) {                                                                    \
-                    half_t * wrow_ = Ws + (buf_) * BN * BK + bnl * BK;                         \
-                    _Pragma("unroll") for (int j = 0; j < 4; j++)                              \
-                        *(h8 *)(wrow_ + (((bkb * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(BR, j), j); \
-                }                                                                              \
-            }                                                                                  \
-        }
-        WS_LOAD(X0, W0, B0, 0);
-        { const int t1 = last < 1 ? last : 1; WS_LOAD(X1, W1, B1, t1); }
-        WS_STORE(X0, W0, B0, 0);
-        __syncthreads();                                   // tile 0 visible
-        for (int kt = 0; kt < nk; kt += 2) {
-            { const int t2 = kt + 2 < last ? kt + 2 : last; WS_LOAD(X0, W0, B0, t2); }
-            WS_STORE(X1, W1, B1, 1);                       // tile kt+1 -> buf1 (compute is on buf0)
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            { const int t3 = kt + 3 < last ? kt + 3 : last; WS_LOAD(X1, W1, B1, t3); }
-            WS_STORE(X0, W0, B0, 0);                       // tile kt+2 -> buf0 (compute is on buf1)
-            __syncthreads();
-        }
-#undef WS_LOAD
-#undef WS_STORE
-    } else {
-    // ================================ COMPUTE waves ================================
-    const int lane = tid & 63;
-    const int wn = wave >> 1, wm = wave & 1;
-    const int frow = lane & 15, fgrp = lane >> 4;
-    f4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; a++)
-#pragma unroll
-        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-#define WS_COMPUTE(buf_)                                                                       \
-    {                                                                                          \
-        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
-        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
-            h8 xf[TM];                                                                         \
-            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
-                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
-            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
-                const h8 wf = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
-                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
-            }                                                                                  \
-        }                                                                                      \
-    }
-    __syncthreads();                                       // tile 0 visible
-    for (int kt = 0; kt < nk; kt += 2) {
-        WS_COMPUTE(0);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        WS_COMPUTE(1);
-        __syncthreads();
-    }
-#undef WS_COMPUTE
-    asm volatile("" ::: "memory");   // keep the epilogue's bias / residual loads below the main loop (register pressure)
-    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-template <int WT, int BM, int BN, int EPI, bool DIRECT>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmParams p) {
-    // WLDS: the weight tile is staged (dequantised) through LDS like X.  !WLDS (DIRECT, quantised types only): every wave
-    // loads its own MFMA A-fragments as packed quants straight into registers and dequantises beside the MFMAs.
-    constexpr bool WLDS = (WT == W_F16) || !DIRECT;
-    constexpr bool WQLDS = WLDS && (WT != W_F16);     // quantised weights through LDS: one 32-weight block per thread per K-step
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
-    half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]   (f16 weights only)
-
-    constexpr int TN = BN / 32;   // 16-row MFMA fragments per wave along N (wave owns BN/2 rows)
-    constexpr int TM = BM / 32;
-    constexpr int XCH = BM * 8 / NTHREADS;            // 16 B chunks of the X tile per thread
-    constexpr int WCH = BN * 8 / NTHREADS;            // (f16 weights) chunks per thread
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
-    const int frow = lane & 15, fgrp = lane >> 4;
-
-    // ---- XCD-aware tile mapping (bijective for any grid size) ----
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int tiles_n = (p.W.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // n fastest: the tiles_n workgroups that share one X row-panel run back to back on one XCD, so the panel is
-    // fetched into that L2 once; the (small) weight matrix stays L2-resident anyway.
-    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.W.Kpad / BK;
-
-    // ---- per-thread global source coordinates (chunk q = tid + i*256 -> row (tid>>3) + 32 i, chunk tid&7) ----
-    const int xrow0 = tid >> 3, xc = tid & 7;
-    const int xlds0 = lds_off(xrow0, xc);     // rows advance by 32 per i: (row & 7) is unchanged -> offset += 32*BK
-    size_t xgoff[XCH];
-#pragma unroll
-    for (int i = 0; i < XCH; i++) {
-        int gm = m0 + xrow0 + 32 * i;
-        gm = gm < p.M ? gm : p.M - 1;          // clamp: rows past M are computed but never stored
-        xgoff[i] = (size_t)gm * p.lda + xc * 8;
-    }
-    const int wrow = n0 + wn * (BN / 2) + frow;   // this lane's weight row of fragment 0 (quantised path)
-
-    u32x4 X0[XCH], X1[XCH];                   // two register stages of the X tile
-    u32x4 W0[WT == W_F16 ? WCH : 1], W1[WT == W_F16 ? WCH : 1];
-    WFrag<WT> F0[WLDS ? 1 : TN * 2], F1[WLDS ? 1 : TN * 2];   // DIRECT: two stages of raw weight fragments [a][kk]
-    RawBlock<WT> B0, B1;                                      // WQLDS: two stages of one raw block per thread
-    const int bnl = tid % BN, bkb = tid / BN;                 // block (row bnl, k-block bkb) of the tile handled by this thread
-    const bool bact = (BN * 2 >= NTHREADS) || tid < BN * 2;
-
-#define LOAD_X(R, kt_)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < XCH; i++) R[i] = *(const u32x4 *)(p.A + xgoff[i] + (kt_) * BK);
-#define STORE_X(R, buf_)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < XCH; i++) *(u32x4 *)(Xs + (buf_) * BM * BK + xlds0 + i * 32 * BK) = R[i];
-#define LOAD_W16(R, B, kt_)                                                                    \
-    if constexpr (WT == W_F16) {                                                               \
-        _Pragma("unroll") for (int i = 0; i < WCH; i++)                                        \
-            R[i] = *(const u32x4 *)((const half_t *)p.W.w16 + (size_t)(n0 + xrow0 + 32 * i) * p.W.Kpad + (kt_) * BK + xc * 8); \
-    } else {                                                                                   \
-        if (bact) load_block<WT>(B, p.W, (size_t)((kt_) * 2 + bkb) * p.W.Npad + n0 + bnl);     \
-    }
-#define STORE_W16(R, B, buf_)                                                                  \
-    if constexpr (WT == W_F16) {                                                               \
-        _Pragma("unroll") for (int i = 0; i < WCH; i++) *(u32x4 *)(Ws + (buf_) * BN * BK + xlds0 + i * 32 * BK) = R[i]; \
-    } else {                                                                                   \
-        if (bact) {                                                                            \
-            half_t * wrow_ = Ws + (buf_) * BN * BK + bnl * BK;                                 \
-            _Pragma("unroll") for (int j = 0; j < 4; j++)                                      \
-                *(h8 *)(wrow_ + (((bkb * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(B, j), j); \
-        }                                                                                      \
-    }
-#define LOAD_WQ(F, kt_)                                                                        \
-    _Pragma("unroll") for (int a = 0; a < TN; a++)                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                       \
-            load_wfrag<WT>(F[a * 2 + kk], p.W, (size_t)((kt_) * 2 + kk) * p.W.Npad + wrow + a * 16, fgrp);
-
-    f4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; a++)
-#pragma unroll
-        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-
-#define COMPUTE(buf_, F)                                                                       \
-    {                                                                                          \
-        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
-        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
-        (void)ws;                                                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
-            h8 xf[TM];                                                                         \
-            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
-                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
-            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
-                h8 wf;                                                                         \
-                if constexpr (WLDS) wf = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
-                else wf = dequant_wfrag<WT>(F[a * 2 + kk], fgrp);                              \
-                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
-            }                                                                                  \
-        }                                                                                      \
-    }
-
-    // ---- main loop.  X (and f16 W): two register stages (tiles k+1, k+2 in flight) + two LDS buffers.
-    //      Quantised W: fragments of tile k+1 are loaded into registers while tile k is multiplied. One barrier per K-step.
-    // Every prefetch is UNCONDITIONAL (tile index clamped to the last tile): a load inside an `if` makes hipcc's
-    // s_waitcnt insertion assume it may not have been issued and fall back to vmcnt(0/1) for the older tile, which
-    // exposes the full memory latency of the tile just requested on every K-step.
-    const int last = nk - 1;
-    LOAD_X(X0, 0);
-    if constexpr (WLDS) { LOAD_W16(W0, B0, 0); } else { LOAD_WQ(F0, 0); }
-    {
-        const int t1 = last < 1 ? last : 1;
-        LOAD_X(X1, t1);
-        if constexpr (WLDS) { LOAD_W16(W1, B1, t1); }
-    }
-    STORE_X(X0, 0);
-    if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        {
-            const int t2 = kt + 2 < last ? kt + 2 : last;
-            LOAD_X(X0, t2);
-            if constexpr (WLDS) { LOAD_W16(W0, B0, t2); }
-            if constexpr (!WLDS) { LOAD_WQ(F1, kt + 1); }
-        }
-        COMPUTE(0, F0);
-        STORE_X(X1, 1);
-        if constexpr (WLDS) { STORE_W16(W1, B1, 1); }
-        __syncthreads();
-        {
-            const int t3 = kt + 3 < last ? kt + 3 : last;
-            LOAD_X(X1, t3);
-            if constexpr (WLDS) { LOAD_W16(W1, B1, t3); }
-            if constexpr (!WLDS) { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_WQ(F0, t2); }
-        }
-        COMPUTE(1, F1);
-        STORE_X(X0, 0);
-        if constexpr (WLDS) { STORE_W16(W0, B0, 0); }
-        __syncthreads();
-    }
-    if (kt < nk) COMPUTE(0, F0);   // odd tail (its X tile was stored by the last iteration / the prologue)
-#undef LOAD_X
-#undef STORE_X
-#undef LOAD_W16
-#undef STORE_W16
-#undef LOAD_WQ
-#undef COMPUTE
-
-    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -638,236 +346,14 @@ void launch_dma(const GemmParams & p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Ring variant (3-slot LDS ring, everything staged by LDS-DMA, two tiles in flight, ONE raw barrier per K-step):
-//   * X tile (and the W tile of f16 weights): global_load_lds_dwordx4, swizzled via the source address as above;
-//   * quantised W tile: the RAW packed blocks are DMA'd (16 B quants + 2/4 B scale (+4 B fifth bits) per block) —
-//     4.5-8.5 bits per weight also inside LDS — and dequantised in registers when a wave builds its MFMA
-//     A-fragment (ds_read_b32 of word g + ds_read_u16 of the scale -> 8 fp16).  No dequantised copy is ever written.
-//   * no VGPR-destination global load exists in the loop, so the waits are hand-counted: after multiplying tile k
-//     a wave waits `vmcnt(NI)` (= its own NI DMA instructions of tile k+2 may stay in flight, those of tile k+1
-//     have landed), then s_barrier publishes every wave's part of tile k+1 and retires slot k%3 for reuse.
-// BN is fixed at 128: each of the 4 waves DMAs exactly one 64-block piece of quants/scales per tile.
-// ---------------------------------------------------------------------------------------------
-template <int WT> struct RingFmt { static constexpr int QB = 16, DB = 2, HB = 0; };
-template <> struct RingFmt<W_Q4_1> { static constexpr int QB = 16, DB = 4, HB = 0; };
-template <> struct RingFmt<W_Q5_0> { static constexpr int QB = 16, DB = 2, HB = 4; };
-template <> struct RingFmt<W_Q5_1> { static constexpr int QB = 16, DB = 4, HB = 4; };
-template <> struct RingFmt<W_Q8_0> { static constexpr int QB = 32, DB = 2, HB = 0; };
-
-#define CLIPAMD_GLDS(gptr_, lptr_, size_) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr_), (__attribute__((address_space(3))) void *)(lptr_), size_, 0, 0)
-
-template <int WT, int BM, int EPI>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_ring_kernel(const GemmParams p) {
-    constexpr int BN = 128;
-    constexpr bool WF16 = (WT == W_F16);
-    using RF = RingFmt<WT>;
-    constexpr int NSLOT = 3;
-    constexpr int XS_BYTES = BM * BK * 2;                                   // one X slot
-    constexpr int WS_BYTES = WF16 ? BN * BK * 2 : 2 * BN * (RF::QB + RF::DB + RF::HB);   // one W slot
-    constexpr int Q_OFF = 0, D_OFF = 2 * BN * RF::QB, H_OFF = D_OFF + 2 * BN * RF::DB;  // planes inside a raw W slot
-    constexpr int TN = BN / 32, TM = BM / 32;
-    constexpr int XPW = BM / 32;                                            // X pieces (1 KB) per wave
-    constexpr int WPW = BN / 32;                                            // f16 W pieces per wave
-    // DMA instructions one wave issues per tile (hand-counted for s_waitcnt vmcnt)
-    constexpr int NI = XPW + (WF16 ? WPW : (RF::QB / 16) + 1 + (RF::HB ? 1 : 0));
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char * Xring = smem_raw;
-    unsigned char * Wring = smem_raw + NSLOT * XS_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
-    const int frow = lane & 15, fgrp = lane >> 4;
-
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int tiles_n = (p.W.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.W.Kpad / BK;
-    const int last = nk - 1;
-
-    // ---- DMA sources ----
-    const int prow = lane >> 3;
-    const int pchunk = (lane & 7) ^ prow;
-    const half_t * xsrc[XPW];
-#pragma unroll
-    for (int i = 0; i < XPW; i++) {
-        int gm = m0 + (wave * XPW + i) * 8 + prow;
-        gm = gm < p.M ? gm : p.M - 1;
-        xsrc[i] = p.A + (size_t)gm * p.lda + pchunk * 8;
-    }
-    const half_t * wsrc[WF16 ? WPW : 1];
-    if constexpr (WF16) {
-#pragma unroll
-        for (int i = 0; i < WPW; i++)
-            wsrc[i] = (const half_t *)p.W.w16 + (size_t)(n0 + (wave * WPW + i) * 8 + prow) * p.W.Kpad + pchunk * 8;
-    }
-    // quantised: wave w owns the 64-block piece (k-block w>>1, rows (w&1)*64 .. +63); lane l its block
-    const int pkb = wave >> 1;
-    const size_t pblk = (size_t)n0 + (wave & 1) * 64 + lane;     // + (kt*2+pkb)*Npad at issue time
-    const int praw = (pkb * BN + (wave & 1) * 64) ;              // first block index of the piece inside a slot plane
-
-#define RING_DMA(slot_, kt_)                                                                   \
-    {                                                                                          \
-        unsigned char * xs_ = Xring + (slot_) * XS_BYTES;                                      \
-        unsigned char * ws_ = Wring + (slot_) * WS_BYTES;                                      \
-        _Pragma("unroll") for (int i = 0; i < XPW; i++)                                        \
-            CLIPAMD_GLDS(xsrc[i] + (kt_) * BK, xs_ + (wave * XPW + i) * 1024, 16);             \
-        if constexpr (WF16) {                                                                  \
-            _Pragma("unroll") for (int i = 0; i < WPW; i++)                                    \
-                CLIPAMD_GLDS(wsrc[i] + (kt_) * BK, ws_ + (wave * WPW + i) * 1024, 16);         \
-        } else {                                                                               \
-            const size_t bi_ = (size_t)((kt_) * 2 + pkb) * p.W.Npad + pblk;                    \
-            if constexpr (RF::QB == 32) {                                                      \
-                CLIPAMD_GLDS((const uint8_t *)p.W.qs + bi_ * 32, ws_ + Q_OFF + praw * 16, 16);            \
-                CLIPAMD_GLDS((const uint8_t *)p.W.qs + bi_ * 32 + 16, ws_ + Q_OFF + 2 * BN * 16 + praw * 16, 16); \
-            } else {                                                                           \
-                CLIPAMD_GLDS((const uint8_t *)p.W.qs + bi_ * 16, ws_ + Q_OFF + praw * 16, 16); \
-            }                                                                                  \
-            if constexpr (RF::DB == 2) { CLIPAMD_GLDS((const uint8_t *)p.W.dm + bi_ * 2, ws_ + D_OFF + praw * 2, 2); } \
-            else { CLIPAMD_GLDS((const uint8_t *)p.W.dm + bi_ * 4, ws_ + D_OFF + praw * 4, 4); } \
-            if constexpr (RF::HB != 0) { CLIPAMD_GLDS((const uint8_t *)p.W.qh + bi_ * 4, ws_ + H_OFF + praw * 4, 4); } \
-        }                                                                                      \
-    }
-
-    f4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; a++)
-#pragma unroll
-        for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-
-#define RING_COMPUTE(slot_)                                                                    \
-    {                                                                                          \
-        const half_t * xs = (const half_t *)(Xring + (slot_) * XS_BYTES);                      \
-        const unsigned char * ws = Wring + (slot_) * WS_BYTES;                                 \
-        _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
-            h8 xf[TM];                                                                         \
-            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
-                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
-            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
-                h8 wf;                                                                         \
-                if constexpr (WF16) {                                                          \
-                    wf = *(const h8 *)((const half_t *)ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
-                } else {                                                                       \
-                    const int blk_ = kk * BN + wn * (BN / 2) + a * 16 + frow;                  \
-                    WFrag<WT> f_;                                                              \
-                    if constexpr (RF::QB == 32) {                                              \
-                        const uint2 q2_ = *(const uint2 *)(ws + Q_OFF + (fgrp >> 1) * (2 * BN * 16) + blk_ * 16 + (fgrp & 1) * 8); \
-                        f_.q = q2_.x; f_.q1 = q2_.y;                                           \
-                    } else {                                                                   \
-                        f_.q = *(const uint32_t *)(ws + Q_OFF + blk_ * 16 + fgrp * 4);         \
-                    }                                                                          \
-                    if constexpr (RF::HB != 0) f_.h = *(const uint32_t *)(ws + H_OFF + blk_ * 4); \
-                    if constexpr (RF::DB == 4) f_.dm = *(const h2 *)(ws + D_OFF + blk_ * 4);   \
-                    else f_.d = *(const half_t *)(ws + D_OFF + blk_ * 2);                      \
-                    wf = dequant_wfrag<WT>(f_, fgrp);                                          \
-                }                                                                              \
-                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
-            }                                                                                  \
-        }                                                                                      \
-    }
-// "my DMA of the older tile has landed" (NI newer instructions may remain in flight), then publish / retire via barrier
-#define RING_SYNC(n_)                                                                          \
-    {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory");                              \
-        __builtin_amdgcn_s_barrier();                                                          \
-        asm volatile("" ::: "memory");                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-    }
-
-    RING_DMA(0, 0);
-    { const int t1 = last < 1 ? last : 1; RING_DMA(1, t1); }
-    RING_SYNC(NI);                                   // tile 0 landed everywhere
-    int slot = 0;                                    // slot of tile kt; tile kt+2 goes to slot+2 (mod 3)
-    for (int kt = 0; kt < nk; kt++) {
-        const int t2 = kt + 2 < last ? kt + 2 : last;
-        const int s2 = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3
-        RING_DMA(s2, t2);
-        RING_COMPUTE(slot);
-        RING_SYNC(NI);                               // tile kt+1 landed everywhere; slot `slot` free again
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the redundant tail prefetches before LDS is released
-#undef RING_DMA
-#undef RING_COMPUTE
-#undef RING_SYNC
-    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
-}
-
-template <int WT, int BM, int EPI>
-void launch_ring(const GemmParams & p, hipStream_t stream) {
-    constexpr int BN = 128;
-    using RF = RingFmt<WT>;
-    constexpr size_t smem = 3 * ((size_t)BM * BK * 2 + (WT == W_F16 ? (size_t)BN * BK * 2 : (size_t)2 * BN * (RF::QB + RF::DB + RF::HB)));
-    static bool attr_set = false;
-    if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<WT, BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_ring_kernel<WT, BM, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
-}
-
-template <int WT, int BM, int BN, int EPI, bool DIRECT>
-void launch_one(const GemmParams & p, hipStream_t stream) {
-    constexpr bool WLDS = (WT == W_F16) || !DIRECT;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
-    const size_t smem = (size_t)2 * (BM + (WLDS ? BN : 0)) * BK * sizeof(half_t);
-    hipLaunchKernelGGL((gemm_kernel<WT, BM, BN, EPI, DIRECT>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
-}
-
-// tile code: variant * 1000000 + BM * 1000 + BN; variant 0 = weights staged through LDS, 1 = per-wave register fragments
-template <int WT, int BM, int BN, int EPI>
-void launch_ws(const GemmParams & p, hipStream_t stream) {
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
-    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
-    hipLaunchKernelGGL((gemm_ws_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(512), smem, stream, p);
-}
-
+// tile code: BM * 1000 + BN  (0 = heuristic)
 template <int WT, int EPI>
 void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
-    if (tile / 1000000 == 4) {   // 3-slot LDS-DMA ring
-        switch (tile % 1000000) {
-        case 64128: launch_ring<WT, 64, EPI>(p, stream); break;
-        default: launch_ring<WT, 128, EPI>(p, stream); break;
-        }
-        return;
-    }
-    if (tile / 1000000 == 3) {   // LDS-DMA staging
-        switch (tile % 1000000) {
-        case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;
-        case 128064: launch_dma<WT, 128, 64, EPI>(p, stream); break;
-        case 64064: launch_dma<WT, 64, 64, EPI>(p, stream); break;
-        default: launch_dma<WT, 128, 128, EPI>(p, stream); break;
-        }
-        return;
-    }
-    if (tile / 1000000 == 2) {   // wave-specialised
-        switch (tile % 1000000) {
-        case 64128: launch_ws<WT, 64, 128, EPI>(p, stream); break;
-        default: launch_ws<WT, 128, 128, EPI>(p, stream); break;
-        }
-        return;
-    }
-    const bool direct = (tile / 1000000) == 1 && WT != W_F16;
     switch (tile % 1000000) {
-    case 128128: direct ? launch_one<WT, 128, 128, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 128, 128, EPI, false>(p, stream); break;
-    case 64128: direct ? launch_one<WT, 64, 128, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 64, 128, EPI, false>(p, stream); break;
-    case 128064: direct ? launch_one<WT, 128, 64, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 128, 64, EPI, false>(p, stream); break;
-    default: direct ? launch_one<WT, 64, 64, EPI, (WT != W_F16)>(p, stream) : launch_one<WT, 64, 64, EPI, false>(p, stream); break;
+    case 128128: launch_dma<WT, 128, 128, EPI>(p, stream); break;
+    case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;
+    case 128064: launch_dma<WT, 128, 64, EPI>(p, stream); break;
+    default: launch_dma<WT, 64, 64, EPI>(p, stream); break;
     }
 }
 
@@ -910,6 +396,8 @@ void launch_gemm_wt2(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
+
+int gemm_tile_for(int M, int N) { return pick_tile(M, N); }
 
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream) {
     if (p.M <= 0) return;

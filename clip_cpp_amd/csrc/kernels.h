@@ -60,6 +60,7 @@ struct GemmParams {
 
 // tile: 0 = heuristic, else BM*1000 + BN with BM,BN in {64,128}
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
+int gemm_tile_for(int M, int N);   // the tile (BM*1000+BN) the heuristic picks for this shape
 
 // LayerNorm over rows of h floats (ggml_norm + mul + add, reference clip.cpp:1350-1355).
 // Row r reads x[in_rows[r]] when in_rows != nullptr, else x[r * in_row_mul] (strided gather, e.g. the
