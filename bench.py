@@ -163,7 +163,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc (scripts/gpu_pmc.sh)
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom)
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roofline = {"bound": "mfma", "kernel": dom + " (dequant + fp16 MFMA GEMM; WT,BM,BN,EPI)", "achieved": round(achieved, 2),

@@ -1,14 +1,35 @@
 #!/bin/bash
-# One gpurun call: GPU test tier + smoke + bench + rocprofv3 kernel trace. Logs under gpurun_out/.
+# One gpurun call: GPU test tier + smoke + bench + rocprofv3 kernel trace (+ PMC HBM traffic). Logs under gpurun_out/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r01}
-echo "== kernels tests" ; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --maxfail=8 2>&1 | tail -40 | tee gpurun_out/${TAG}_kernels.log
-echo "== parity tests" ; timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=12 2>&1 | tail -60 | tee gpurun_out/${TAG}_parity.log
-echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -5 | tee gpurun_out/${TAG}_smoke.log
-echo "== bench" ; timeout 900 python bench.py --steps 10 --warmup 3 --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -5 | tee gpurun_out/${TAG}_bench.log
-echo "== rocprof" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > /tmp/prof_${TAG}.log 2>&1; tail -3 /tmp/prof_${TAG}.log)
-find /tmp/prof_${TAG} -type f | head -20; for f in $(find /tmp/prof_${TAG} -name "*kernel_stats*.csv"); do cp $f gpurun_out/${TAG}_kernel_stats.csv; done
-head -30 gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
+echo "== kernels tests" ; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | tail -5 | tee gpurun_out/${TAG}_kernels.log
+echo "== parity tests" ; timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -15 | tee gpurun_out/${TAG}_parity.log
+echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
+echo "== bench" ; timeout 900 python bench.py --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -2 | cut -c1-3000 | tee gpurun_out/${TAG}_bench.log
+echo "== rocprof kernel trace" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
+for f in $(find /tmp/prof_${TAG} -name "*kernel_stats*.csv"); do grep -v "at::native\|__amd_rocclr" $f | cut -c1-400 > gpurun_out/${TAG}_kernel_stats.csv; done
+head -8 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200
+echo "== rocprof PMC (HBM traffic)"
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$set -o pmc -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_${TAG}_$set.log 2>&1)
+done
+python - <<PY | tee gpurun_out/${TAG}_pmc_traffic.txt
+import csv, glob, collections, json
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for f in glob.glob("/tmp/pmc_${TAG}_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "clipamd" not in k: continue
+        k = k.replace("void clipamd::(anonymous namespace)::", "").split("(")[0].replace(" ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+out = {}
+for k in acc:
+    fs = acc[k].get("FETCH_SIZE", 0) / max(1, cnt[(k, "FETCH_SIZE")]); ws = acc[k].get("WRITE_SIZE", 0) / max(1, cnt[(k, "WRITE_SIZE")])
+    # rocprofv3 units: KB per dispatch; gfx950 correction (MI355X_MICROARCH.md): FETCH_SIZE reads 1/2 of a wide coalesced stream -> x2
+    out[k] = {"fetch_kb_raw": fs, "write_kb_raw": ws, "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0, "launches": cnt[(k, "FETCH_SIZE")]}
+    print("%-60s FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  -> HBM bytes/launch (fetch x2) %.3e  [%d launches]" % (k[:60], fs, ws, out[k]["hbm_bytes_per_launch"], cnt[(k, "FETCH_SIZE")]))
+json.dump(out, open("gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
+PY
