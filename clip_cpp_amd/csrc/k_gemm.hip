@@ -282,20 +282,32 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
     for (int a = 0; a < TN; a++)
 #pragma unroll
         for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+// All 16 fragment reads of a K-step are issued up front (both 32-wide k-slices) and pinned above the MFMA block:
+// left to itself hipcc re-uses fragment registers and puts an s_waitcnt lgkmcnt(0) in front of every group of
+// 4-8 MFMAs (four exposed LDS round trips per K-step: the ds_read+MFMA loop alone then tops out at ~44 % of the
+// MFMA peak); in this order the waits become counted (lgkmcnt(15..0)) and only the first round trip is exposed.
 #define COMPUTE(buf_)                                                                          \
     {                                                                                          \
         const half_t * xs = Xs + (buf_) * BM * BK;                                             \
         const half_t * ws = Ws + (buf_) * BN * BK;                                             \
+        h8 xf[2][TM], wf[2][TN];                                                               \
         _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
-            h8 xf[TM];                                                                         \
+            _Pragma("unroll") for (int a = 0; a < TN; a++)                                     \
+                wf[kk][a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
             _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
-                xf[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
-            _Pragma("unroll") for (int a = 0; a < TN; a++) {                                   \
-                const h8 wf = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
-                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[b], acc[a][b], 0, 0, 0); \
-            }                                                                                  \
+                xf[kk][b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fgrp)); \
         }                                                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                       \
+            _Pragma("unroll") for (int a = 0; a < TN; a++)                                     \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][b], acc[a][b], 0, 0, 0); \
+        /* schedule: the TN+TM reads of slice 0, then slice-0 MFMAs with the slice-1 reads slotted in, then slice-1 MFMAs */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                               \
+        _Pragma("unroll") for (int i = 0; i < TN + TM; i++) {                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, (TN * TM) / (TN + TM), 0);             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+        }                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0); \
     }
 
     DMA_TILE(0, 0);
