@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--ftype", default="q4_0")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--texts", type=int, default=-1, help="texts per GPU per step (default = batch)")
+    ap.add_argument("--vision-only", action="store_true", help="vision tower only (implies --texts 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
@@ -69,11 +70,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    n_texts = args.batch if args.texts < 0 else args.texts
+    n_texts = 0 if args.vision_only else (args.batch if args.texts < 0 else args.texts)
     cache = os.environ.get("CLIP_AMD_FIXTURE_CACHE", "/tmp/clip_amd_fixtures")
-    path = fixtures.cached_model(cache, args.model, args.ftype, text=True, vision=True, seed=1234)
+    path = fixtures.cached_model(cache, args.model, args.ftype, text=not args.vision_only, vision=True, seed=1234)
     clip = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
     vc, tc = clip.vision_config, clip.text_config
+    if args.vision_only:
+        tc = dict(tc, num_positions=77)
     S, proj = vc["image_size"], vc["projection_dim"]
     # a dedicated (non-null) torch stream carries the HIP kernels AND the RCCL all-gather, so they are ordered
     stream = torch.cuda.Stream()
@@ -184,7 +187,7 @@ def main():
         cores = ref.host_cores()
         t = time.perf_counter()
         want = orc.image_batch_encode(h_imgs, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=cores)
-        for ids in texts[:ns]:
+        for ids in (texts[:ns] if n_texts else []):
             orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=cores)
         cdt = time.perf_counter() - t
         got = img_out[:ns].cpu().numpy()
@@ -192,7 +195,7 @@ def main():
         torch.cuda.synchronize()
         got = img_out[:ns].cpu().numpy()
         cosd = 1.0 - (got * want).sum(1)
-        cpu_baseline = {"value": round(2 * ns / cdt, 3), "unit": "embeddings/s", "cores": cores, "kind": "port",
+        cpu_baseline = {"value": round((2 if n_texts else 1) * ns / cdt, 3), "unit": "embeddings/s", "cores": cores, "kind": "port",
                         "sample": "%d images + %d texts of the same workload, oracle in ggml-faithful numerics (CPU restatement of the ggml path; ggml @dd1d575 unavailable)" % (ns, ns),
                         "gpu_vs_cpu_1_minus_cos_max": float(cosd.max()), "gpu_vs_cpu_1_minus_cos_mean": float(cosd.mean())}
 
