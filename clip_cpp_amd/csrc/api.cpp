@@ -148,15 +148,13 @@ bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, 
     }
     (void)hipSetDevice(ctx->device);
     const int chunk = 256;
-    void * d_in = nullptr;
-    void * d_out = nullptr;
     const int cmax = std::min(B, chunk);
-    if (hipMalloc(&d_in, per * 4 * cmax) != hipSuccess || hipMalloc(&d_out, (size_t)proj * 4 * cmax) != hipSuccess) {
-        (void)hipGetLastError();
-        if (d_in) (void)hipFree(d_in);
+    if (!ensure_io(ctx, per * 4 * cmax, (size_t)proj * 4 * cmax)) {
         fprintf(stderr, "clip_image_batch_encode: out of device memory\n");
         return false;
     }
+    void * d_in = ctx->io_in;
+    void * d_out = ctx->io_out;
     bool ok = true;
     for (int b0 = 0; b0 < B && ok; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
@@ -167,8 +165,6 @@ bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, 
         ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
     }
     if (!ok) fprintf(stderr, "clip_image_batch_encode: HIP error: %s\n", hipGetErrorString(hipGetLastError()));
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
     if (ctx->profiling) prof_collect(ctx);
     return ok;
 }

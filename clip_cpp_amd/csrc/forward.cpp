@@ -144,9 +144,18 @@ bool launch_ok(const char * who) {
 
 }  // namespace
 
+void drop_graphs(clip_ctx * ctx) {
+    for (auto & g : ctx->vgraphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->vgraphs.clear();
+}
+
 bool ensure_workspace(clip_ctx * ctx, size_t bytes) {
     if (ctx->ws.bytes >= bytes) return true;
     (void)hipStreamSynchronize(ctx->stream);
+    drop_graphs(ctx);   // captured graphs hold pointers into the old workspace
     if (ctx->ws.base) (void)hipFree(ctx->ws.base);
     ctx->ws.base = nullptr;
     ctx->ws.bytes = 0;
@@ -173,6 +182,20 @@ bool ensure_pinned(clip_ctx * ctx, size_t bytes) {
     return true;
 }
 
+bool ensure_io(clip_ctx * ctx, size_t in_bytes, size_t out_bytes) {
+    auto grow = [&](void *& p, size_t & have, size_t want) {
+        if (have >= want) return true;
+        (void)hipStreamSynchronize(ctx->stream);
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        have = 0;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+        have = want;
+        return true;
+    };
+    return grow(ctx->io_in, ctx->io_in_bytes, in_bytes) && grow(ctx->io_out, ctx->io_out_bytes, out_bytes);
+}
+
 void prof_collect(clip_ctx * ctx) {
     if (ctx->pending.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
@@ -192,8 +215,48 @@ void prof_collect(clip_ctx * ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------
+static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize);
+
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
+    if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 64 || !ctx->has_vision_encoder)
+        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);   // big batches are GPU-bound: no graph needed
+    clip_ctx::GraphEntry * e = nullptr;
+    for (auto & g : ctx->vgraphs)
+        if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize) { e = &g; break; }
+    if (e && e->exec) return hipGraphLaunch(e->exec, ctx->stream) == hipSuccess;
+    if (!e) {   // first sighting: run eagerly (allocates the workspace, sets kernel attributes)
+        if (ctx->vgraphs.size() >= 16) drop_graphs(ctx);
+        ctx->vgraphs.push_back({B, d_imgs, d_out, normalize, 1, nullptr, nullptr});
+        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    }
+    // second sighting: capture
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    }
+    const bool ok = vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+    if (!ok || ce != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        ctx->graphs_enabled = false;   // capture not possible here: stay eager from now on
+        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(graph);
+        ctx->graphs_enabled = false;
+        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    }
+    e->graph = graph;
+    e->exec = exec;
+    return hipGraphLaunch(exec, ctx->stream) == hipSuccess;
+}
+
+static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
         return false;

@@ -382,6 +382,7 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     if (device < 0 || device >= ndev) return fail("invalid HIP device ordinal " + std::to_string(device));
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
     ctx->device = device;
+    { const char * g = getenv("CLIP_AMD_GRAPHS"); if (g && g[0] == '0') ctx->graphs_enabled = false; }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     ctx->stream = ctx->own_stream;
     ctx->weights_bytes = L.st.buf.size() + 256;
@@ -398,9 +399,12 @@ void free_model(clip_ctx * ctx) {
         (void)hipSetDevice(ctx->device);
         if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
         for (auto & p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        drop_graphs(ctx);
         if (ctx->ws.base) (void)hipFree(ctx->ws.base);
         if (ctx->weights_base) (void)hipFree(ctx->weights_base);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        if (ctx->io_in) (void)hipFree(ctx->io_in);
+        if (ctx->io_out) (void)hipFree(ctx->io_out);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;

@@ -78,12 +78,22 @@ struct clip_ctx {
     clipamd::Workspace ws;           // activations, grown on demand
     void * pinned = nullptr;         // pinned host staging
     size_t pinned_bytes = 0;
+    void * io_in = nullptr;          // persistent device staging of the host-pointer API (stable pointers -> graph hits)
+    size_t io_in_bytes = 0;
+    void * io_out = nullptr;
+    size_t io_out_bytes = 0;
 
     // profiling (HIP events on the ctx stream)
     bool profiling = false;
     struct PendingEvent { hipEvent_t a, b; std::string tag; double flops, bytes; };
     std::vector<PendingEvent> pending;
     std::map<std::string, clipamd::ProfEntry> prof;
+
+    // hipGraph cache for the vision forward (launch-bound at small batch: ~90 launches per pass).  A pass is captured the
+    // second time the same (batch, input pointer, output pointer, normalize) signature is seen and replayed afterwards.
+    struct GraphEntry { int B; const void * in; void * out; bool norm; int seen; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> vgraphs;
+    bool graphs_enabled = true;      // CLIP_AMD_GRAPHS=0 disables
 
     int verbosity = 0;
     std::string path;
@@ -102,7 +112,9 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
                          bool normalize);
 bool ensure_workspace(clip_ctx * ctx, size_t bytes);
 bool ensure_pinned(clip_ctx * ctx, size_t bytes);
+bool ensure_io(clip_ctx * ctx, size_t in_bytes, size_t out_bytes);
 void prof_collect(clip_ctx * ctx);
+void drop_graphs(clip_ctx * ctx);
 
 // host pieces
 bool tokenize_text(const clip_ctx * ctx, const char * text, std::vector<int32_t> & out);            // tokenizer.cpp

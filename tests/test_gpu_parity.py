@@ -168,3 +168,21 @@ def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
     clip.encode_texts_device(d_ids.data_ptr(), off, d_t.data_ptr())
     torch.cuda.synchronize()
     np.testing.assert_allclose(d_t.cpu().numpy(), clip.encode_texts(texts), atol=1e-6)
+
+
+def test_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
+    """Small batches are captured into a hipGraph on the 2nd call with the same signature and replayed afterwards:
+    eager (1st) == capture (2nd) == replay (3rd...), and a replay sees new pixel data written into the same buffers."""
+    p = fixtures.cached_model(fixture_cache, "tiny14", "q4_0")
+    clip = gpu.Clip(p, device=0)
+    a = fixtures.synthetic_images(3, 28, seed=41)
+    b = fixtures.synthetic_images(3, 28, seed=42)
+    ea = clip.encode_images(a)              # eager
+    for _ in range(4):                      # capture, then replays
+        assert np.array_equal(clip.encode_images(a), ea)
+    eb = clip.encode_images(b)              # replay on new data
+    assert not np.array_equal(ea, eb)
+    clip2 = gpu.Clip(p, device=0)           # fresh context: eager reference for b
+    assert np.array_equal(clip2.encode_images(b), eb)
+    one = clip.encode_images(a[:1])         # different batch -> different signature
+    assert np.array_equal(one[0], ea[0])
