@@ -186,3 +186,38 @@ def test_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
     assert np.array_equal(clip2.encode_images(b), eb)
     one = clip.encode_images(a[:1])         # different batch -> different signature
     assert np.array_equal(one[0], ea[0])
+
+
+def test_reference_example_main_runs_unchanged_on_the_gpu_library(gpu, fixture_cache, tmp_path):
+    """BASELINE config 1 ("plumbing"): the reference's examples/main.cpp, compiled unchanged against include/ and linked to
+    libclip.so (oracle/_ref/ref_main, built in the dev container by `make -C oracle ref`), loads a ViT-B/32 f16 two-tower GGUF,
+    decodes a JPEG, tokenizes, encodes both towers on the GPU and prints the similarity score."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_main")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_main not built (needs the reference tree)")
+    PIL = pytest.importorskip("PIL.Image")
+    p = fixtures.cached_model(fixture_cache, "b32", "f16")
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:300, 0:400]
+    img = np.clip(np.stack([(np.sin(xx / 29.0) * 0.5 + 0.5) * 255, (np.cos(yy / 19.0) * 0.5 + 0.5) * 255, (xx + 2 * yy) % 256], -1)
+                  + rng.normal(0, 6, (300, 400, 3)), 0, 255).astype(np.uint8)
+    jpg = str(tmp_path / "photo.jpg")
+    PIL.fromarray(img).save(jpg, "JPEG", quality=90, progressive=True)
+    text = "a photo of a red apple"
+    out = subprocess.run([exe, "-m", p, "--image", jpg, "--text", text, "-v", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"Similarity score = ([-0-9.]+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    # oracle composition on the same decoded pixels
+    L = gpu.lib()
+    u8 = L.clip_image_u8_make()
+    assert L.clip_image_load_from_file(os.fsencode(jpg), u8)
+    pix = np.ctypeslib.as_array(u8.contents.data, shape=(u8.contents.ny, u8.contents.nx, 3)).copy()
+    L.clip_image_u8_free(u8)
+    orc = ref.OracleModel(p)
+    ie = orc.image_batch_encode(orc.preprocess(pix)[None], normalize=True)[0]
+    te = orc.text_encode(orc.tokenize(text), normalize=True)
+    assert abs(float(m.group(1)) - ref.similarity(ie, te)) < 2e-3, (m.group(1), ref.similarity(ie, te))
