@@ -354,7 +354,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
 template <int WT, int BM, int BN, int EPI>
 void launch_dma(const GemmParams & p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
-    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+    static bool attr_set = false;   // dynamic LDS above 64 KB needs the opt-in once per kernel
+    if (smem > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)gemm_dma_kernel<WT, BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
     hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
 }
 
@@ -363,6 +368,8 @@ template <int WT, int EPI>
 void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
     switch (tile % 1000000) {
     case 128128: launch_dma<WT, 128, 128, EPI>(p, stream); break;
+    case 160128: launch_dma<WT, 160, 128, EPI>(p, stream); break;
+    case 192128: launch_dma<WT, 192, 128, EPI>(p, stream); break;
     case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;
     case 128064: launch_dma<WT, 128, 64, EPI>(p, stream); break;
     default: launch_dma<WT, 64, 64, EPI>(p, stream); break;
@@ -381,14 +388,27 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
     }
 }
 
-// Tile heuristic: biggest tile that still yields >= ~1 workgroup per CU (256 CUs).
+// Tile heuristic, fitted to scripts/gemm_bench.py measurements (profiles/README.md).  Small problems take the smallest
+// tiles (most workgroups).  Otherwise BN = 128 and BM in {64, 128, 160, 192} minimising
+//     g(tiles / 512) x (BM + 32)            [x 1.15 for BM = 64]
+// where 512 = 256 CUs x 2 co-resident workgroups, BM + 32 models the per-tile cost (the +32 is the W dequant that does
+// not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
+// one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
+// 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
 int pick_tile(int M, int N) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return N >= 2048 ? 64128 : 64064;
-    if (wgs(128, 128) >= 384) return 128128;
-    if (wgs(64, 128) >= 256) return 64128;
-    if (wgs(128, 128) >= 200) return 128128;
-    return 64064;
+    if (wgs(128, 128) < 100) return wgs(64, 128) >= 256 ? 64128 : 64064;
+    int best = 128128;
+    float best_cost = 0.f;
+    const int cand[4] = {128, 160, 192, 64};
+    for (int bm : cand) {
+        const float x = (float)wgs(bm, 128) / 512.f;
+        const float g = x <= 0.5f ? 0.7f : x <= 1.f ? 1.f : 0.75f * x + 0.25f * ceilf(x);
+        const float cost = g * (float)(bm + 32) * (bm == 64 ? 1.15f : 1.f);
+        if (best_cost == 0.f || cost < best_cost) { best_cost = cost; best = bm * 1000 + 128; }
+    }
+    return best;
 }
 
 }  // namespace

@@ -81,7 +81,7 @@ def test_gemm_all_weight_types_vs_dequant_reference(L, tname, shape):
     assert rel < (5e-4 if tname in ("f16", "f32") else 2e-2), rel
 
 
-@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128])
+@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128])
 @pytest.mark.parametrize("tname", ["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     """Every tile shape accumulates each output in the same k order -> identical bits; also exercises M/N edges."""
