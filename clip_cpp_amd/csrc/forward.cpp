@@ -65,7 +65,9 @@ double weight_bytes(const DevWeight & W) {
     return 0;
 }
 
-void gemm(clip_ctx * ctx, const char * what, const GemmParams & p, int epi) {
+void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
+    GemmParams p = p0;
+    p.sk_ws = ctx->sk_ws; p.sk_ws_floats = ctx->sk_ws_floats; p.sk_cnt = ctx->sk_cnt; p.sk_cnt_n = ctx->sk_cnt_n;
     if (!ctx->profiling) {
         launch_gemm(p, epi, 0, ctx->stream);
         return;

@@ -206,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
 // (the barrier's vmcnt(0) is what lands the DMA, so nothing inside a step waits on memory).
 // ---------------------------------------------------------------------------------------------
 template <int WT, int BM, int BN, int EPI>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2 : 1)) gemm_dma_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half_t * Xs = (half_t *)smem_raw;                 // [2][BM*BK]
     half_t * Ws = Xs + 2 * BM * BK;                   // [2][BN*BK]
@@ -222,16 +222,24 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
 
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.W.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
+    constexpr bool SK = (BM == 64);
+    const int nwg = tiles_m * tiles_n * (SK ? p.ksplit : 1);
     int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7;
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+    // split-K (BM = 64 tiles only, small-M problems): ksplit consecutive workgroups share one output tile, each
+    // multiplying a contiguous range of K-steps; see the fix-up after the main loop.
+    const int ksplit = SK ? p.ksplit : 1;
+    const int tile_id = SK ? bid / ksplit : bid;
+    const int split = SK ? bid - tile_id * ksplit : 0;
+    const int tile_n = tile_id % tiles_n, tile_m = tile_id / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = p.W.Kpad / BK;
+    const int nk_all = p.W.Kpad / BK;
+    const int kbeg = SK ? (split * nk_all) / ksplit : 0;
+    const int nk = SK ? ((split + 1) * nk_all) / ksplit - kbeg : nk_all;
     const int last = nk - 1;
 
     // DMA source addresses: piece = wave*XPW + i covers tile rows piece*8 .. +7
@@ -242,16 +250,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
     for (int i = 0; i < XPW; i++) {
         int gm = m0 + (wave * XPW + i) * 8 + prow;
         gm = gm < p.M ? gm : p.M - 1;
-        xsrc[i] = p.A + (size_t)gm * p.lda + pchunk * 8;
+        xsrc[i] = p.A + (size_t)gm * p.lda + pchunk * 8 + kbeg * BK;
     }
     const half_t * wsrc[WT == W_F16 ? WPW : 1];
     if constexpr (WT == W_F16) {
 #pragma unroll
         for (int i = 0; i < WPW; i++)
-            wsrc[i] = (const half_t *)p.W.w16 + (size_t)(n0 + (wave * WPW + i) * 8 + prow) * p.W.Kpad + pchunk * 8;
+            wsrc[i] = (const half_t *)p.W.w16 + (size_t)(n0 + (wave * WPW + i) * 8 + prow) * p.W.Kpad + pchunk * 8 + kbeg * BK;
     }
-    RawBlock<WT> B0, B1;
-    const int bnl = tid % BN, bkb = tid / BN;
+    // quantised W: the tile is BN rows x 2 blocks; thread t owns blocks t, t + 256, ... (block id = kb * BN + row)
+    constexpr int NB = (BN * 2 + NTHREADS - 1) / NTHREADS;
+    RawBlock<WT> B0[NB], B1[NB];
+    const int bnl = tid % BN, bkb = tid / BN;          // NB > 1 (BN = 256): block i is (row bnl, k-block i)
     const bool bact = (BN * 2 >= NTHREADS) || tid < BN * 2;
 
 #define DMA_TILE(buf_, kt_)                                                                    \
@@ -267,14 +277,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
     }
 #define LOAD_B(B, kt_)                                                                         \
     if constexpr (WT != W_F16) {                                                               \
-        if (bact) load_block<WT>(B, p.W, (size_t)((kt_) * 2 + bkb) * p.W.Npad + n0 + bnl);     \
+        if (bact) {                                                                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++)                                  \
+                load_block<WT>(B[i_], p.W, (size_t)(((kt_) + kbeg) * 2 + bkb + i_ * (NTHREADS / BN)) * p.W.Npad + n0 + bnl); \
+        }                                                                                      \
     }
 #define STORE_B(B, buf_)                                                                       \
     if constexpr (WT != W_F16) {                                                               \
         if (bact) {                                                                            \
             half_t * wrow_ = Ws + (buf_) * BN * BK + bnl * BK;                                 \
-            _Pragma("unroll") for (int j = 0; j < 4; j++)                                      \
-                *(h8 *)(wrow_ + (((bkb * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(B, j), j); \
+            _Pragma("unroll") for (int i_ = 0; i_ < NB; i_++)                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; j++)                                  \
+                    *(h8 *)(wrow_ + ((((bkb + i_ * (NTHREADS / BN)) * 4 + j) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(B[i_], j), j); \
         }                                                                                      \
     }
     f4 acc[TN][TM];
@@ -348,6 +362,53 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_dma_kernel(const GemmParams 
 #undef STORE_B
 #undef COMPUTE
     asm volatile("" ::: "memory");
+    if constexpr (SK) {
+        if (ksplit > 1) {
+            // Deterministic split-K fix-up: every workgroup parks its partial tile in the workspace ([tile][split][frag][thread]
+            // float4, coalesced); the LAST one to arrive (per-tile ticket counter, self-resetting) re-reads all ksplit partials
+            // in split order 0..ksplit-1 — the same summation order whoever arrives last — and runs the epilogue.
+            // Hand-off without cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility): partials are written
+            // with agent-scope (sc1, write-through) stores, drained with s_waitcnt vmcnt(0) before the ticket, and read
+            // back with agent-scope loads that bypass the non-coherent L1 / per-XCD L2 copies.
+            __shared__ int is_last;
+            typedef unsigned long long u64;
+            u64 * part = (u64 *)(p.sk_ws + ((size_t)tile_id * ksplit) * (BM * BN));
+            constexpr int PER_SPLIT = BM * BN / 2;     // u64 per partial tile
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++) {
+                    const float2 lo = make_float2(acc[a][b][0], acc[a][b][1]), hi = make_float2(acc[a][b][2], acc[a][b][3]);
+                    u64 * dst = part + (size_t)split * PER_SPLIT + ((a * TM + b) * 2) * NTHREADS + tid;
+                    __hip_atomic_store(dst, __builtin_bit_cast(u64, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + NTHREADS, __builtin_bit_cast(u64, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned ticket = __hip_atomic_fetch_add(p.sk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                is_last = (ticket == (unsigned)ksplit - 1u);
+                if (is_last) __hip_atomic_store(p.sk_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+            }
+            __syncthreads();
+            if (!is_last) return;
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < ksplit; sp++) {
+#pragma unroll
+                for (int a = 0; a < TN; a++)
+#pragma unroll
+                    for (int b = 0; b < TM; b++) {
+                        const u64 * src = part + (size_t)sp * PER_SPLIT + ((a * TM + b) * 2) * NTHREADS + tid;
+                        const float2 lo = __builtin_bit_cast(float2, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        const float2 hi = __builtin_bit_cast(float2, __hip_atomic_load(src + NTHREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        acc[a][b] += (f4){lo.x, lo.y, hi.x, hi.y};
+                    }
+            }
+        }
+    }
     gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
 }
 
@@ -360,7 +421,9 @@ void launch_dma(const GemmParams & p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void *)gemm_dma_kernel<WT, BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(tiles_m * tiles_n), dim3(NTHREADS), smem, stream, p);
+    int grid = tiles_m * tiles_n;
+    if (BM == 64) grid *= p.ksplit;   // p.ksplit validated by launch_gemm
+    hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(grid), dim3(NTHREADS), smem, stream, p);
 }
 
 // tile code: BM * 1000 + BN  (0 = heuristic)
@@ -370,6 +433,8 @@ void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
     case 128128: launch_dma<WT, 128, 128, EPI>(p, stream); break;
     case 160128: launch_dma<WT, 160, 128, EPI>(p, stream); break;
     case 192128: launch_dma<WT, 192, 128, EPI>(p, stream); break;
+    // BN = 256 tiles (128..256 x 256, one workgroup per CU, accumulators in AGPRs) compile and are correct but measured
+    // 10-40 % slower than the two-workgroups-per-CU tiles above (profiles/r01_gemm_bigtile_experiment.txt): not instantiated.
     case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;
     case 128064: launch_dma<WT, 128, 64, EPI>(p, stream); break;
     default: launch_dma<WT, 64, 64, EPI>(p, stream); break;
@@ -397,7 +462,7 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
 int pick_tile(int M, int N) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (M <= 64) return N >= 2048 ? 64128 : 64064;
+    if (M <= 64) return 64064;
     if (wgs(128, 128) < 100) return wgs(64, 128) >= 256 ? 64128 : 64064;
     int best = 128128;
     float best_cost = 0.f;
@@ -431,9 +496,33 @@ void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
 int gemm_tile_for(int M, int N) { return pick_tile(M, N); }
 
-void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream) {
-    if (p.M <= 0) return;
-    if (tile == 0) tile = pick_tile(p.M, p.W.N);
+// Split-K factor for a BM = 64 tile grid (small-M problems: batch 1 / 32, single texts), fitted with
+// scripts/gemm_bench.py (profiles/r01_gemm_splitk.txt): a K-step costs ~0.5 us of serial latency, the fix-up ~3 us, so
+// splitting pays when the K loop is long — ksplit ~ sqrt(nk / 1.5) (12 steps -> 3, 48 -> 6) — and, once the grid already
+// fills the chip (>= 256 tiles), only for the long-K GEMMs (FFN down) and at most 4-way.
+int pick_ksplit(int tiles, int nk) {
+    if (nk < 8) return 1;
+    int ks = (int)(sqrtf((float)nk / 1.5f) + 0.5f);
+    if (tiles >= 256) ks = nk >= 32 ? (ks < 4 ? ks : 4) : 1;
+    if (tiles * ks > 1536) ks = 1536 / tiles;
+    return ks < 1 ? 1 : ks > 16 ? 16 : ks;
+}
+
+void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stream) {
+    if (p0.M <= 0) return;
+    GemmParams p = p0;
+    const bool heuristic = (tile == 0);
+    int ksplit = tile / 1000000;        // explicit: ksplit * 1000000 + BM * 1000 + BN  (no prefix = no split)
+    tile %= 1000000;
+    if (heuristic) tile = pick_tile(p.M, p.W.N);
+    const int bm = tile / 1000, bn = tile % 1000;
+    const int tiles = ((p.M + bm - 1) / bm) * ((p.W.N + bn - 1) / bn), nk = p.W.Kpad / BK;
+    if (heuristic) ksplit = pick_ksplit(tiles, nk);
+    if (ksplit < 1) ksplit = 1;
+    if (bm != 64 || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n) ksplit = 1;
+    if (ksplit > nk / 2) ksplit = nk / 2 > 0 ? nk / 2 : 1;
+    while (ksplit > 1 && (size_t)tiles * ksplit * bm * bn > p.sk_ws_floats) ksplit--;
+    p.ksplit = ksplit;
     switch (p.W.wtype) {
     case W_F16: launch_gemm_wt0(p, epilogue, tile, stream); break;
     case W_Q4_0: launch_gemm_wt1(p, epilogue, tile, stream); break;

@@ -55,10 +55,17 @@ struct GemmParams {
     int qcols = 0;
     int Np = 0, T = 0;
     const float * pos = nullptr;
+    // split-K (small-M problems): workspace for partial tiles + per-tile ticket counters (zeroed once; the kernel leaves
+    // them zero).  ksplit is chosen by launch_gemm; 1 = off.  Null workspace = never split.
+    float * sk_ws = nullptr;
+    size_t sk_ws_floats = 0;
+    unsigned * sk_cnt = nullptr;
+    int sk_cnt_n = 0;
+    int ksplit = 1;
     int debug = 0;   // ablation switches for kernel tuning (scripts/gemm_bench.py): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
 };
 
-// tile: 0 = heuristic, else BM*1000 + BN with BM,BN in {64,128}
+// tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
 int gemm_tile_for(int M, int N);   // the tile (BM*1000+BN) the heuristic picks for this shape
 

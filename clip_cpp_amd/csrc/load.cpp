@@ -385,6 +385,13 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     { const char * g = getenv("CLIP_AMD_GRAPHS"); if (g && g[0] == '0') ctx->graphs_enabled = false; }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     ctx->stream = ctx->own_stream;
+    {   // split-K workspace (small-M GEMMs): 16 MB of partial tiles + 4096 ticket counters
+        const size_t nfl = (size_t)4 << 20;
+        void * w = nullptr, * c = nullptr;
+        if (hipMalloc(&w, nfl * sizeof(float)) != hipSuccess || hipMalloc(&c, 4096 * sizeof(unsigned)) != hipSuccess || hipMemset(c, 0, 4096 * sizeof(unsigned)) != hipSuccess)
+            return fail("hipMalloc (split-K workspace) failed");
+        ctx->sk_ws = (float *)w; ctx->sk_ws_floats = nfl; ctx->sk_cnt = (unsigned *)c; ctx->sk_cnt_n = 4096;
+    }
     ctx->weights_bytes = L.st.buf.size() + 256;
     if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");
     if (hipMemcpy(ctx->weights_base, L.st.buf.data(), L.st.buf.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("weight upload failed");
@@ -405,6 +412,8 @@ void free_model(clip_ctx * ctx) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         if (ctx->io_in) (void)hipFree(ctx->io_in);
         if (ctx->io_out) (void)hipFree(ctx->io_out);
+        if (ctx->sk_ws) (void)hipFree(ctx->sk_ws);
+        if (ctx->sk_cnt) (void)hipFree(ctx->sk_cnt);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;

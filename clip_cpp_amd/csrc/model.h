@@ -82,6 +82,11 @@ struct clip_ctx {
     size_t io_in_bytes = 0;
     void * io_out = nullptr;
     size_t io_out_bytes = 0;
+    // split-K workspace of the GEMM (kernels.h GemmParams::sk_*): partial tiles + per-tile ticket counters (kept zero)
+    float * sk_ws = nullptr;
+    size_t sk_ws_floats = 0;
+    unsigned * sk_cnt = nullptr;
+    int sk_cnt_n = 0;
 
     // profiling (HIP events on the ctx stream)
     bool profiling = false;

@@ -16,11 +16,32 @@ SHAPES = [  # (name, M, N, K, epi)
     ("b32.qkv", 12800, 2304, 768, 1), ("b32.out", 12800, 768, 768, 4), ("b32.up", 12800, 3072, 768, 3), ("b32.down", 12800, 768, 3072, 4),
     ("b32.b32.up", 1600, 3072, 768, 3), ("b32.b32.down", 1600, 768, 3072, 4),
     ("l14.up", 65792, 4096, 1024, 3), ("l14.down", 65792, 1024, 4096, 4),
+    ("b1.qkv", 50, 2304, 768, 1), ("b1.out", 50, 768, 768, 4), ("b1.up", 50, 3072, 768, 3), ("b1.down", 50, 768, 3072, 4),
+    ("b32.b32.qkv", 1600, 2304, 768, 1), ("b32.b32.out", 1600, 768, 768, 4),
+    ("txt.qkv", 10290, 1536, 512, 1), ("txt.out", 10290, 512, 512, 4), ("txt.up", 10290, 2048, 512, 3), ("txt.down", 10290, 512, 2048, 4),
 ]
 tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
 types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
 only = [a for a in sys.argv[1:] if "." in a]
 debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]
+if "blas" in sys.argv[1:]:
+    # yardstick: the vendor library (hipBLASLt / rocBLAS through torch) on the same shapes, plain f16 x f16 -> f16, no epilogue
+    for name, M, N, K, epi in SHAPES:
+        if only and name not in only:
+            continue
+        x = torch.randn(M, K, device="cuda", dtype=torch.float16)
+        w = torch.randn(N, K, device="cuda", dtype=torch.float16)
+        for _ in range(3):
+            y = torch.nn.functional.linear(x, w)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            y = torch.nn.functional.linear(x, w)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        print("blas  %-14s M=%6d N=%5d K=%5d | %8.1f us %7.1f TF" % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6), flush=True)
+    sys.exit(0)
 for tname in types:
     for name, M, N, K, epi in SHAPES:
         if only and name not in only:

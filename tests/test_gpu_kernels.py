@@ -95,6 +95,29 @@ def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     assert np.array_equal(base, y)
 
 
+@pytest.mark.parametrize("ksplit,tile", [(2, 64064), (3, 64064), (5, 64128), (12, 64064)])
+@pytest.mark.parametrize("tname,epi", [("q4_0", 4), ("f16", 1), ("q8_0", 3), ("q5_1", 0)])
+def test_gemm_split_k_is_deterministic_and_matches_unsplit(L, ksplit, tile, tname, epi):
+    """Small-M path: K split over `ksplit` workgroups per tile with the in-kernel ordered fix-up.  Two runs give the
+    same bits (summation order does not depend on arrival order); the result differs from the unsplit one only by
+    fp32 re-association."""
+    rng = np.random.default_rng(100 + ksplit)
+    M, N, K = 50, 320, 1536
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    code = ksplit * 1000000 + tile
+    a = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=code)
+    b = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=code)
+    assert np.array_equal(a, b)
+    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + tile)
+    assert np.abs(a - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
+    auto = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=0)     # heuristic (splits here)
+    assert np.abs(auto - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
+
+
 @pytest.mark.parametrize("epi", [1, 2, 3, 4])
 def test_gemm_epilogues(L, epi):
     rng = np.random.default_rng(7 + epi)
