@@ -61,6 +61,7 @@ API_SYMBOLS = [
 AMD_SYMBOLS = [
     "clip_amd_device_count", "clip_amd_model_load", "clip_amd_ctx_device", "clip_amd_set_stream",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
+    "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
     "clip_amd_test_gemm", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
@@ -130,6 +131,10 @@ def lib():
     L.clip_amd_synchronize.argtypes = [vp]
     L.clip_amd_image_batch_encode_device.restype = C.c_bool
     L.clip_amd_image_batch_encode_device.argtypes = [vp, vp, i32, vp, C.c_bool]
+    L.clip_amd_image_batch_preprocess_device.restype = C.c_bool
+    L.clip_amd_image_batch_preprocess_device.argtypes = [vp, C.POINTER(ClipImageU8), i32, vp]
+    L.clip_amd_image_batch_encode_u8.restype = C.c_bool
+    L.clip_amd_image_batch_encode_u8.argtypes = [vp, C.POINTER(ClipImageU8), i32, f32p, C.c_bool]
     L.clip_amd_text_batch_encode_device.restype = C.c_bool
     L.clip_amd_text_batch_encode_device.argtypes = [vp, vp, C.POINTER(C.c_int32), i32, vp, C.c_bool]
     L.clip_amd_profile_enable.argtypes = [vp, C.c_bool]
@@ -268,6 +273,30 @@ class Clip:
         out = np.ctypeslib.as_array(res.data, shape=(S, S, 3)).copy()
         lib().clip_image_f32_clean(C.byref(res))
         return out
+
+    @staticmethod
+    def _u8_array(images):
+        keep = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        arr = (ClipImageU8 * len(keep))()
+        for i, im in enumerate(keep):
+            arr[i] = ClipImageU8(im.shape[1], im.shape[0], im.ctypes.data_as(C.POINTER(C.c_uint8)), im.size)
+        return keep, arr
+
+    def encode_images_u8(self, images, normalize=True):
+        """list of uint8 [ny,nx,3] raw images (any sizes) -> float32 [n,proj]; resize/crop/normalise run on the GPU
+        (clip_amd_image_batch_encode_u8), bit-identical to preprocess() + encode_images()."""
+        keep, arr = self._u8_array(images)
+        out = np.empty((len(keep), self.vision_config["projection_dim"]), dtype=np.float32)
+        if not lib().clip_amd_image_batch_encode_u8(self.ctx, arr, len(keep), _fp(out), normalize):
+            raise RuntimeError("clip_amd_image_batch_encode_u8 failed (see stderr)")
+        return out
+
+    def preprocess_device(self, images, d_out_ptr):
+        """list of uint8 [ny,nx,3] raw images -> [n,S,S,3] float32 at device address d_out_ptr (asynchronous)."""
+        keep, arr = self._u8_array(images)
+        if not lib().clip_amd_image_batch_preprocess_device(self.ctx, arr, len(keep), C.c_void_p(d_out_ptr)):
+            raise RuntimeError("clip_amd_image_batch_preprocess_device failed (see stderr)")
+        self.synchronize()   # `keep` (the host pixels) must outlive the copy into the pinned blob — it does: the copy is synchronous
 
     def encode_images(self, imgs, normalize=True):
         """float32 [B,S,S,3] preprocessed images (host) -> float32 [B,proj] via clip_image_batch_encode."""

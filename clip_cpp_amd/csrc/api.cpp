@@ -184,6 +184,51 @@ bool clip_amd_image_batch_encode_device(struct clip_ctx * ctx, const float * d_i
     return vision_forward_device(ctx, d_imgs, batch, d_out, normalize);
 }
 
+bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * d_out) {
+    return preprocess_batch_device(ctx, imgs, n, d_out);
+}
+
+// raw u8 images -> embeddings with the resize/crop/normalise on the GPU (bit-identical to clip_image_preprocess):
+// ships <= 3 B/pixel of the ORIGINAL image instead of 12 B/pixel of the resized one and takes the double-precision
+// resampling (the dominant host cost of benchmark.cpp / zsl.cpp style callers) off the CPU.
+bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * vec, bool normalize) {
+    if (!ctx->has_vision_encoder) {
+        printf("This gguf file seems to have no vision encoder\n");
+        return false;
+    }
+    if (ctx->device < 0) {
+        fprintf(stderr, "clip_amd_image_batch_encode_u8: no HIP device bound to this context — the encoders have no CPU fallback\n");
+        return false;
+    }
+    if (n <= 0) return true;
+    const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
+    const size_t per = (size_t)S * S * 3;
+    (void)hipSetDevice(ctx->device);
+    bool ok = true;
+    int b0 = 0;
+    while (b0 < n && ok) {
+        // chunk: at most 256 images and ~512 MB of raw pixels
+        int bc = 0;
+        size_t bytes = 0;
+        while (b0 + bc < n && bc < 256 && (bc == 0 || bytes < ((size_t)512 << 20))) {
+            bytes += (size_t)3 * (size_t)std::max(0, imgs[b0 + bc].nx) * (size_t)std::max(0, imgs[b0 + bc].ny);
+            bc++;
+        }
+        if (!ensure_io(ctx, per * 4 * std::min(n, 256), (size_t)proj * 4 * std::min(n, 256))) {
+            fprintf(stderr, "clip_amd_image_batch_encode_u8: out of device memory\n");
+            return false;
+        }
+        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in);
+        ok = ok && vision_forward_device(ctx, (const float *)ctx->io_in, bc, (float *)ctx->io_out, normalize);
+        ok = ok && hipMemcpyAsync(vec + (size_t)b0 * proj, ctx->io_out, (size_t)proj * 4 * bc, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        b0 += bc;
+    }
+    if (!ok) fprintf(stderr, "clip_amd_image_batch_encode_u8: failed (%s)\n", hipGetErrorString(hipGetLastError()));
+    if (ctx->profiling) prof_collect(ctx);
+    return ok;
+}
+
 bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_tokens * tokens, size_t n_texts, float * vec,
                             const bool normalize) {
     (void)n_threads;

@@ -96,6 +96,21 @@ void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int
 // out[r][:] = v[r][:] / ||v[r]||_2  (reference clip.cpp:1446-1455) or plain copy when !normalize
 void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream);
 
+// GPU image preprocessing (k_preproc.hip; reference clip.cpp:728-1008): separable antialiased bicubic resize of the
+// shorter side to S, centre crop, normalise.  Tap tables come from the host (preprocess.cpp) so that the result is
+// bit-identical to the host path.
+struct PreImg {            // one per image
+    long long src_off;     // byte offset of the [ny][nx][3] u8 pixels in `raw`
+    int nx, ny;            // source size
+    int x0, y0;            // crop origin in the resized image
+    int ylo, nrows;        // first source row the vertical pass needs / number of such rows
+    long long hbuf_off;    // float offset of this image's horizontal-pass rows [nrows][S][3] in `hbuf`
+    int th, tv;            // tap-table indices (horizontal, vertical)
+};
+struct PreTaps { long long w_off; int first_off, count_off, ksize; };   // weights [out][ksize] in wpool; first/count [out] in ipool
+void launch_preprocess(const uint8_t * raw, const PreImg * imgs, const PreTaps * taps, const double * wpool, const int * ipool, float * hbuf,
+                       float * out, int n_imgs, int S, int max_rows, const float * mean, const float * stdv, hipStream_t stream);
+
 // fp32 -> fp16 conversion of a [rows][cols] matrix into a padded fp16 matrix (test hooks / inputs)
 void launch_f32_to_f16(const float * src, int lds, half_t * dst, int ldd, int rows, int cols, int cols_pad,
                        hipStream_t stream);

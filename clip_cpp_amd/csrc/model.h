@@ -82,6 +82,8 @@ struct clip_ctx {
     size_t io_in_bytes = 0;
     void * io_out = nullptr;
     size_t io_out_bytes = 0;
+    void * pre_buf = nullptr;        // device blob of the GPU preprocessing path (descriptors, taps, raw pixels, row buffer)
+    size_t pre_bytes = 0;
     // split-K workspace of the GEMM (kernels.h GemmParams::sk_*): partial tiles + per-tile ticket counters (kept zero)
     float * sk_ws = nullptr;
     size_t sk_ws_floats = 0;
@@ -124,6 +126,7 @@ void drop_graphs(clip_ctx * ctx);
 // host pieces
 bool tokenize_text(const clip_ctx * ctx, const char * text, std::vector<int32_t> & out);            // tokenizer.cpp
 bool preprocess_image(const clip_ctx * ctx, const clip_image_u8 * img, clip_image_f32 * res);      // preprocess.cpp
+bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out);     // preprocess.cpp + k_preproc.hip
 bool load_image_file(const char * fname, clip_image_u8 * img);                                      // image_io.cpp
 
 // quant.cpp — host codecs for the ggml block formats

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -131,6 +133,111 @@ bool preprocess_image(const clip_ctx * ctx, const clip_image_u8 * img, clip_imag
         }
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device path: the same resize/crop/normalise on the GPU (k_preproc.hip).  The host computes the tap
+// tables (one per distinct (source size, target size) pair), packs {descriptors, tables, raw u8 pixels} into one pinned
+// blob, ships it with a single H2D copy and launches the two passes.  d_out: [n][S][S][3] f32 in HBM.
+// ---------------------------------------------------------------------------------------------
+bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out) {
+    if (!ctx->has_vision_encoder) {
+        printf("This gguf file seems to have no vision encoder\n");
+        return false;
+    }
+    if (ctx->device < 0) {
+        fprintf(stderr, "clip_amd_image_batch_preprocess_device: no HIP device bound to this context\n");
+        return false;
+    }
+    if (n <= 0) return true;
+    const int S = ctx->vision_hparams.image_size;
+    std::vector<PreImg> desc(n);
+    std::vector<PreTaps> dir;
+    std::vector<double> wpool;
+    std::vector<int> ipool;
+    std::map<std::pair<int, int>, int> seen;
+    std::vector<Taps> tabs;
+    auto table = [&](int in_size, int out_size) {
+        auto it = seen.find({in_size, out_size});
+        if (it != seen.end()) return it->second;
+        Taps t = make_taps(in_size, out_size);
+        PreTaps e;
+        e.w_off = (long long)wpool.size();
+        e.first_off = (int)ipool.size();
+        e.count_off = e.first_off + out_size;
+        e.ksize = t.ksize;
+        wpool.insert(wpool.end(), t.w.begin(), t.w.end());
+        ipool.insert(ipool.end(), t.first.begin(), t.first.end());
+        ipool.insert(ipool.end(), t.count.begin(), t.count.end());
+        dir.push_back(e);
+        tabs.push_back(std::move(t));
+        const int idx = (int)dir.size() - 1;
+        seen[{in_size, out_size}] = idx;
+        return idx;
+    };
+    size_t raw_bytes = 0, hbuf_floats = 0;
+    int max_rows = 0;
+    for (int i = 0; i < n; i++) {
+        const clip_image_u8 & im = imgs[i];
+        if (im.nx <= 0 || im.ny <= 0 || !im.data) {
+            fprintf(stderr, "clip_amd_image_batch_preprocess_device: image %d is empty\n", i);
+            return false;
+        }
+        const float scale = std::min((float)im.nx, (float)im.ny) / (float)S;   // same arithmetic as preprocess_image above
+        const int rx = (int)(im.nx / scale + 0.5f), ry = (int)(im.ny / scale + 0.5f);
+        if (rx < S || ry < S) {
+            fprintf(stderr, "clip_amd_image_batch_preprocess_device: image %d (%dx%d) resizes below %d\n", i, im.nx, im.ny, S);
+            return false;
+        }
+        PreImg & d = desc[i];
+        d.nx = im.nx; d.ny = im.ny;
+        d.x0 = (rx - S) / 2; d.y0 = (ry - S) / 2;
+        d.th = table(im.nx, rx);
+        d.tv = table(im.ny, ry);
+        const Taps & tv = tabs[d.tv];
+        d.ylo = tv.first[d.y0];
+        int yhi = 0;
+        for (int o = d.y0; o < d.y0 + S; o++) yhi = std::max(yhi, tv.first[o] + tv.count[o]);
+        d.nrows = yhi - d.ylo;
+        max_rows = std::max(max_rows, d.nrows);
+        d.src_off = (long long)raw_bytes;
+        raw_bytes += ((size_t)3 * im.nx * im.ny + 15) & ~(size_t)15;
+        d.hbuf_off = (long long)hbuf_floats;
+        hbuf_floats += (size_t)d.nrows * S * 3;
+    }
+    // blob layout (all 16-byte aligned): descriptors | directory | ipool | wpool | raw pixels ; then (device only) hbuf
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_desc = 0, o_dir = up(o_desc + desc.size() * sizeof(PreImg)), o_ip = up(o_dir + dir.size() * sizeof(PreTaps));
+    const size_t o_wp = up(o_ip + ipool.size() * sizeof(int)), o_raw = up(o_wp + wpool.size() * sizeof(double));
+    const size_t host_bytes = up(o_raw + raw_bytes), total = host_bytes + hbuf_floats * sizeof(float);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);   // the pinned blob / device buffer of the previous call may still be in use
+    if (!ensure_pinned(ctx, host_bytes)) { fprintf(stderr, "clip (hip): cannot pin %zu MB\n", host_bytes >> 20); return false; }
+    if (ctx->pre_bytes < total) {
+        if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
+        ctx->pre_buf = nullptr; ctx->pre_bytes = 0;
+        if (hipMalloc(&ctx->pre_buf, total) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "clip (hip): cannot allocate %zu MB for preprocessing\n", total >> 20); return false; }
+        ctx->pre_bytes = total;
+    }
+    uint8_t * h = (uint8_t *)ctx->pinned;
+    memcpy(h + o_desc, desc.data(), desc.size() * sizeof(PreImg));
+    memcpy(h + o_dir, dir.data(), dir.size() * sizeof(PreTaps));
+    memcpy(h + o_ip, ipool.data(), ipool.size() * sizeof(int));
+    memcpy(h + o_wp, wpool.data(), wpool.size() * sizeof(double));
+    {
+        const int nthr = std::max(1, std::min(8, n));     // the pixel copy into pinned memory is the host cost of this path
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; t++)
+            pool.emplace_back([&, t]() {
+                for (int i = t; i < n; i += nthr) memcpy(h + o_raw + desc[i].src_off, imgs[i].data, (size_t)3 * imgs[i].nx * imgs[i].ny);
+            });
+        for (auto & th : pool) th.join();
+    }
+    uint8_t * dv = (uint8_t *)ctx->pre_buf;
+    if (hipMemcpyAsync(dv, h, host_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+    launch_preprocess(dv + o_raw, (const PreImg *)(dv + o_desc), (const PreTaps *)(dv + o_dir), (const double *)(dv + o_wp), (const int *)(dv + o_ip),
+                      (float *)(dv + host_bytes), d_out, n, S, max_rows, ctx->image_mean, ctx->image_std, ctx->stream);
+    return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace clipamd

@@ -35,6 +35,16 @@ void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream);
 bool clip_amd_image_batch_encode_device(struct clip_ctx * ctx, const float * d_imgs, int batch, float * d_out,
                                         bool normalize);
 
+/* GPU image preprocessing ("next" row §8f-1; reference clip_image_preprocess / clip_image_batch_preprocess,
+ * clip.cpp:728-1008): n raw RGB u8 images of any size (HOST pointers, clip_image_u8 as filled by
+ * clip_image_load_from_file) -> d_out [n][S][S][3] float32 in HBM, resized (antialiased bicubic, shorter side -> S),
+ * centre-cropped and normalised exactly like clip_image_preprocess (bit-identical).  Asynchronous on the ctx stream. */
+bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * d_out);
+
+/* clip_image_batch_preprocess + clip_image_batch_encode in one call with the preprocessing on the GPU.
+ * vec: [n][projection_dim] on the host.  Same results as the two-step host path. */
+bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * vec, bool normalize);
+
 /* Batched text encoding ("next" row §8f-2; per-text semantics identical to
  * clip_text_encode, reference clip.cpp:1016-1233).  Texts are ragged:
  * tokens[i].data holds tokens[i].size ids incl. BOS/EOS.  vec: [n_texts][projection_dim]. */

@@ -177,6 +177,34 @@ def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
     np.testing.assert_allclose(d_t.cpu().numpy(), clip.encode_texts(texts), atol=1e-6)
 
 
+@pytest.mark.parametrize("config,S", [("tiny", 32), ("b32", 224)])
+def test_gpu_preprocessing_is_bit_identical_to_host(gpu, fixture_cache, config, S):
+    """resize / centre-crop / normalise on the GPU (clip_amd_image_batch_preprocess_device) against the host
+    implementation of clip_image_preprocess (itself bit-exact vs the oracle, tests/test_host_api.py): identical bits for
+    down-scaling, up-scaling, extreme aspect ratios and already-square inputs, in one mixed-size batch."""
+    torch = pytest.importorskip("torch")
+    p = fixtures.cached_model(fixture_cache, config, "q4_0", text=False, vision=True)
+    clip = gpu.Clip(p, device=0)
+    rng = np.random.default_rng(77)
+    sizes = [(45, 70), (S, S), (375, 500), (500, 375), (S, 3 * S + 1), (1000, 37), (17, 23), (1, 1), (S + 1, S - 1), (768, 1024)]
+    images = [rng.integers(0, 256, size=(ny, nx, 3), dtype=np.uint8) for ny, nx in sizes]
+    images[2][:] = 255            # saturated image: exercises the clamp after each pass
+    images[3][::2] = 0
+    d_out = torch.full((len(images), S, S, 3), float("nan"), dtype=torch.float32, device="cuda")
+    clip.preprocess_device(images, d_out.data_ptr())
+    got = d_out.cpu().numpy()
+    for i, im in enumerate(images):
+        want = clip.preprocess(im)
+        assert np.array_equal(got[i], want), (i, sizes[i], np.abs(got[i] - want).max())
+    # end to end: raw u8 -> embeddings == host preprocess + encode, bit for bit
+    emb = clip.encode_images_u8(images)
+    want = clip.encode_images(np.stack([clip.preprocess(im) for im in images]))
+    assert np.array_equal(emb, want)
+    # a second, differently shaped batch through the same context (buffers are re-used / re-grown)
+    more = [rng.integers(0, 256, size=(ny, nx, 3), dtype=np.uint8) for ny, nx in [(300, 200), (64, 64), (90, 400)]]
+    assert np.array_equal(clip.encode_images_u8(more), clip.encode_images(np.stack([clip.preprocess(im) for im in more])))
+
+
 def test_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
     """Small batches are captured into a hipGraph on the 2nd call with the same signature and replayed afterwards:
     eager (1st) == capture (2nd) == replay (3rd...), and a replay sees new pixel data written into the same buffers."""

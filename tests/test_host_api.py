@@ -122,6 +122,8 @@ def test_host_only_context_refuses_to_encode(tiny_ctx, clip_lib):
         c.encode_images(np.zeros((1, 32, 32, 3), dtype=np.float32))
     with pytest.raises(RuntimeError):
         c.encode_text([49406, 5, 49407])
+    with pytest.raises(RuntimeError):      # the GPU preprocessing path has no host fallback either
+        c.encode_images_u8([np.zeros((40, 50, 3), dtype=np.uint8)])
 
 
 TEXTS = ["a photo of a cat", "", " ", "  leading  spaces ", "dog's 42!!", "isn't it're've'm'll'd", "tab\there\nnew", "x  ", "  ",
