@@ -62,6 +62,7 @@ AMD_SYMBOLS = [
     "clip_amd_device_count", "clip_amd_model_load", "clip_amd_ctx_device", "clip_amd_set_stream",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
+    "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
     "clip_amd_test_gemm", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
@@ -133,6 +134,10 @@ def lib():
     L.clip_amd_image_batch_encode_device.argtypes = [vp, vp, i32, vp, C.c_bool]
     L.clip_amd_image_batch_preprocess_device.restype = C.c_bool
     L.clip_amd_image_batch_preprocess_device.argtypes = [vp, C.POINTER(ClipImageU8), i32, vp]
+    L.clip_amd_zero_shot_score_device.restype = C.c_bool
+    L.clip_amd_zero_shot_score_device.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+    L.clip_amd_zero_shot_label_images.restype = C.c_bool
+    L.clip_amd_zero_shot_label_images.argtypes = [vp, C.POINTER(ClipImageU8), i32, C.POINTER(C.c_char_p), C.c_size_t, f32p, C.POINTER(C.c_int)]
     L.clip_amd_image_batch_encode_u8.restype = C.c_bool
     L.clip_amd_image_batch_encode_u8.argtypes = [vp, C.POINTER(ClipImageU8), i32, f32p, C.c_bool]
     L.clip_amd_text_batch_encode_device.restype = C.c_bool
@@ -290,6 +295,18 @@ class Clip:
         if not lib().clip_amd_image_batch_encode_u8(self.ctx, arr, len(keep), _fp(out), normalize):
             raise RuntimeError("clip_amd_image_batch_encode_u8 failed (see stderr)")
         return out
+
+    def zero_shot_label_images(self, images, labels):
+        """Batched clip_zero_shot_label_image on the GPU: list of uint8 [ny,nx,3] images x list of label strings ->
+        (scores [B,n] sorted descending, indices [B,n])."""
+        keep, arr = self._u8_array(images)
+        n = len(labels)
+        lab = (C.c_char_p * n)(*[l.encode("utf-8") for l in labels])
+        scores = np.empty((len(keep), n), dtype=np.float32)
+        idx = np.empty((len(keep), n), dtype=np.int32)
+        if not lib().clip_amd_zero_shot_label_images(self.ctx, arr, len(keep), lab, n, _fp(scores), idx.ctypes.data_as(C.POINTER(C.c_int))):
+            raise RuntimeError("clip_amd_zero_shot_label_images failed (see stderr)")
+        return scores, idx
 
     def preprocess_device(self, images, d_out_ptr):
         """list of uint8 [ny,nx,3] raw images -> [n,S,S,3] float32 at device address d_out_ptr (asynchronous)."""

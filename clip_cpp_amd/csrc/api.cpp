@@ -352,6 +352,64 @@ bool clip_zero_shot_label_image(struct clip_ctx * ctx, const int n_threads, cons
     return softmax_with_sorting(sims.data(), (int)n_labels, scores, indices);
 }
 
+// ---- batched zero-shot on the GPU: preprocessing, both towers and the scoring stay on the device ----
+bool clip_amd_zero_shot_score_device(struct clip_ctx * ctx, const float * d_img, int n_images, const float * d_txt, int n_labels, int dim,
+                                     float * d_scores, int * d_indices) {
+    if (!ctx || ctx->device < 0) {
+        fprintf(stderr, "clip_amd_zero_shot_score_device: no HIP device bound to this context\n");
+        return false;
+    }
+    if (!launch_zero_shot(d_img, n_images, d_txt, n_labels, dim, d_scores, d_indices, ctx->stream)) {
+        fprintf(stderr, "clip_amd_zero_shot_score_device: unsupported size (n_labels %d > 8192 or dim %d > 4096)\n", n_labels, dim);
+        return false;
+    }
+    return hipGetLastError() == hipSuccess;
+}
+
+bool clip_amd_zero_shot_label_images(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n_images, const char ** labels,
+                                     size_t n_labels, float * scores, int * indices) {
+    if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
+        printf("clip_zero_shot_label_image function can only be used with two-tower models\n");
+        return false;
+    }
+    if (ctx->device < 0) {
+        fprintf(stderr, "clip_amd_zero_shot_label_images: no HIP device bound to this context — no CPU fallback\n");
+        return false;
+    }
+    if (n_images <= 0 || n_labels == 0) return true;
+    const int dim = ctx->vision_hparams.projection_dim, S = ctx->vision_hparams.image_size;
+    if (ctx->text_hparams.projection_dim != dim) return false;
+    std::vector<int32_t> ids, off(n_labels + 1, 0);
+    std::vector<int32_t> one;
+    for (size_t i = 0; i < n_labels; i++) {
+        if (!tokenize_text(ctx, labels[i], one)) return false;
+        ids.insert(ids.end(), one.begin(), one.end());
+        off[i + 1] = (int32_t)ids.size();
+    }
+    (void)hipSetDevice(ctx->device);
+    const int chunk = std::min(n_images, 256);
+    DBuf d_ids(ids.size() * 4), d_txt(n_labels * (size_t)dim * 4), d_sc((size_t)chunk * n_labels * 4), d_ix((size_t)chunk * n_labels * 4);
+    if (!d_ids.p || !d_txt.p || !d_sc.p || !d_ix.p || !ensure_io(ctx, (size_t)S * S * 12 * chunk, (size_t)dim * 4 * chunk)) {
+        fprintf(stderr, "clip_amd_zero_shot_label_images: out of device memory\n");
+        return false;
+    }
+    // labels once, un-normalised like the reference (clip.cpp:1639-1653) ...
+    bool ok = hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && text_forward_device(ctx, (const int32_t *)d_ids.p, off.data(), (int)n_labels, (float *)d_txt.p, false);
+    // ... then the images in chunks: u8 -> preprocess -> vision tower -> scores, all on the device
+    for (int b0 = 0; b0 < n_images && ok; b0 += chunk) {
+        const int bc = std::min(chunk, n_images - b0);
+        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in);
+        ok = ok && vision_forward_device(ctx, (const float *)ctx->io_in, bc, (float *)ctx->io_out, false);
+        ok = ok && clip_amd_zero_shot_score_device(ctx, (const float *)ctx->io_out, bc, (const float *)d_txt.p, (int)n_labels, dim, (float *)d_sc.p, (int *)d_ix.p);
+        ok = ok && hipMemcpyAsync(scores + (size_t)b0 * n_labels, d_sc.p, (size_t)bc * n_labels * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(indices + (size_t)b0 * n_labels, d_ix.p, (size_t)bc * n_labels * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (ctx->profiling) prof_collect(ctx);
+    return ok;
+}
+
 // ---- quantizer (reference clip.cpp:1661-1844): re-emit the GGUF with 2-D "*weight" tensors quantised ----
 bool clip_model_quantize(const char * fname_inp, const char * fname_out, const int itype) {
     switch (itype) {

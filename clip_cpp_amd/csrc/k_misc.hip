@@ -233,6 +233,68 @@ void launch_cls_rows(float * x, const float * class_embd, const float * pos, int
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * h + 255) / 256), dim3(256), 0, stream, x, class_embd, pos, B, T, h);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Zero-shot scoring (reference clip_similarity_score + softmax_with_sorting, clip.cpp:1525-1532,1591-1622,
+// as composed by clip_zero_shot_label_image :1624-1659 and tests/benchmark.cpp:114-160): one workgroup per image.
+//   sims[j]  = sum_i img[i]*txt[j][i]      sequential fp32 accumulation in i order (bit-identical to the host loop)
+//   e[j]     = (float)(exp((double)sims[j]) + 1e-9);  p[j] = (float)(e[j] / sum_j e[j])   (sum in double)
+//   output   = p sorted descending (ties: lower label index first = the host's stable sort) + the label indices.
+// Sort: bitonic network over (p, index) pairs in LDS, n padded to a power of two (<= 8192).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) zero_shot_kernel(const float * img, const float * txt, int n, int dim, int npad, float * scores, int * indices) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zs_smem[];
+    float * key = (float *)zs_smem;            // [npad]
+    int * idx = (int *)(key + npad);           // [npad]
+    float * iv = (float *)(idx + npad);        // [dim]
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < dim; i += 256) iv[i] = img[(size_t)b * dim + i];
+    __syncthreads();
+    double part = 0.0;
+    for (int j = tid; j < npad; j += 256) {
+        float e = -1.0f;                       // padding sorts last (every real probability is > 0)
+        if (j < n) {
+            const float * t = txt + (size_t)j * dim;
+            float dot = 0.0f;
+            for (int i = 0; i < dim; i++) dot += iv[i] * t[i];
+            e = (float)(exp((double)dot) + 1e-9);
+            part += (double)e;
+        }
+        key[j] = e;
+        idx[j] = j;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double sum = red[0];
+    for (int j = tid; j < n; j += 256) key[j] = (float)((double)key[j] / sum);
+    __syncthreads();
+    // descending bitonic sort; order relation: (a before b) <=> key_a > key_b || (key_a == key_b && idx_a < idx_b)
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npad; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float ka = key[i], kb = key[l];
+                    const int ia = idx[i], ib = idx[l];
+                    const bool a_first = ka > kb || (ka == kb && ia < ib);
+                    const bool up = (i & k) == 0;          // this sub-sequence is sorted "first elements first"
+                    if (up ? !a_first : a_first) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < n; j += 256) {
+        scores[(size_t)b * n + j] = key[j];
+        indices[(size_t)b * n + j] = idx[j];
+    }
+}
+
 static size_t raw_row_bytes(int type, int k) {
     switch (type) {
     case 0: return (size_t)k * 4;
@@ -256,6 +318,22 @@ void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int
 void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream) {
     if (rows <= 0) return;
     hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, v, out, rows, n, normalize ? 1 : 0);
+}
+
+bool launch_zero_shot(const float * img, int B, const float * txt, int n, int dim, float * scores, int * indices, hipStream_t stream) {
+    if (B <= 0 || n <= 0) return true;
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    if (npad > 8192) return false;
+    const size_t smem = (size_t)npad * 8 + (size_t)dim * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)zero_shot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 4096 * 4);
+        attr_set = true;
+    }
+    if (dim > 4096) return false;
+    hipLaunchKernelGGL(zero_shot_kernel, dim3(B), dim3(256), smem, stream, img, txt, n, dim, npad, scores, indices);
+    return true;
 }
 
 void launch_f32_to_f16(const float * src, int lds, half_t * dst, int ldd, int rows, int cols, int cols_pad,

@@ -111,6 +111,10 @@ struct PreTaps { long long w_off; int first_off, count_off, ksize; };   // weigh
 void launch_preprocess(const uint8_t * raw, const PreImg * imgs, const PreTaps * taps, const double * wpool, const int * ipool, float * hbuf,
                        float * out, int n_imgs, int S, int max_rows, const float * mean, const float * stdv, hipStream_t stream);
 
+// Zero-shot scoring: per image, softmax_with_sorting (reference clip.cpp:1591-1622) of its similarities with n text
+// embeddings.  img [B][dim], txt [n][dim] -> scores [B][n] (descending), indices [B][n].  false if n > 8192 or dim > 4096.
+bool launch_zero_shot(const float * img, int B, const float * txt, int n, int dim, float * scores, int * indices, hipStream_t stream);
+
 // fp32 -> fp16 conversion of a [rows][cols] matrix into a padded fp16 matrix (test hooks / inputs)
 void launch_f32_to_f16(const float * src, int lds, half_t * dst, int ldd, int rows, int cols, int cols_pad,
                        hipStream_t stream);

@@ -56,6 +56,20 @@ bool clip_text_batch_encode(const struct clip_ctx * ctx, const int n_threads, co
 bool clip_amd_text_batch_encode_device(struct clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets,
                                        int n_texts, float * d_out, bool normalize);
 
+/* GPU-side zero-shot scoring ("next" row §8f-2; reference clip_similarity_score + softmax_with_sorting as composed by
+ * clip_zero_shot_label_image, clip.cpp:1624-1659, and tests/benchmark.cpp:114-160).  For each of n_images embeddings
+ * d_img [n_images][dim]: similarities with d_txt [n_labels][dim] (sequential fp32 dot, same order as the host),
+ * exp(x)+1e-9 normalised by the double-precision sum, sorted descending -> d_scores / d_indices [n_images][n_labels].
+ * All pointers are HBM addresses; asynchronous on the ctx stream.  n_labels <= 8192, dim <= 4096. */
+bool clip_amd_zero_shot_score_device(struct clip_ctx * ctx, const float * d_img, int n_images, const float * d_txt, int n_labels, int dim,
+                                     float * d_scores, int * d_indices);
+
+/* Batched clip_zero_shot_label_image: raw u8 images (host) x labels -> scores / indices [n_images][n_labels] (host), per
+ * image exactly what clip_zero_shot_label_image returns.  Labels are encoded once (one ragged text batch), images are
+ * preprocessed, encoded and scored on the GPU. */
+bool clip_amd_zero_shot_label_images(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n_images, const char ** labels,
+                                     size_t n_labels, float * scores, int * indices);
+
 /* Block until everything queued on the ctx stream has finished. */
 void clip_amd_synchronize(struct clip_ctx * ctx);
 

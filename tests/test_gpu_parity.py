@@ -205,6 +205,54 @@ def test_gpu_preprocessing_is_bit_identical_to_host(gpu, fixture_cache, config, 
     assert np.array_equal(clip.encode_images_u8(more), clip.encode_images(np.stack([clip.preprocess(im) for im in more])))
 
 
+def test_batched_zero_shot_on_gpu_matches_per_image_reference_composition(gpu, fixture_cache):
+    """clip_amd_zero_shot_label_images (labels encoded once, images preprocessed + encoded + scored on the
+    GPU) == clip_zero_shot_label_image called per image (host scoring with the reference arithmetic)."""
+    import ctypes as C
+    p = fixtures.cached_model(fixture_cache, "tiny", "q8_0")
+    clip = gpu.Clip(p, device=0)
+    rng = np.random.default_rng(5)
+    images = [rng.integers(0, 256, size=(ny, nx, 3), dtype=np.uint8) for ny, nx in [(45, 70), (64, 64), (100, 33), (32, 32), (80, 120)]]
+    labels = ["cat", "dog", "red apple", "a photo of a car", "tree", "cat", "the quick brown fox", "x", "sky", "a", "b c d"]   # incl. a duplicate (tie)
+    scores, idx = clip.zero_shot_label_images(images, labels)
+    assert scores.shape == (5, len(labels)) and idx.shape == (5, len(labels))
+    for i, im in enumerate(images):
+        u8 = gpu.ClipImageU8(im.shape[1], im.shape[0], im.ctypes.data_as(C.POINTER(C.c_uint8)), im.size)
+        s1, i1 = clip.zero_shot_label_pixels(C.byref(u8), labels)
+        np.testing.assert_allclose(scores[i], s1, rtol=1e-5, atol=1e-7)
+        assert list(idx[i]) == i1, (i, list(idx[i]), i1)
+        assert abs(scores[i].sum() - 1.0) < 1e-5 and np.all(np.diff(scores[i]) <= 0)
+        assert sorted(idx[i]) == list(range(len(labels)))
+
+
+@pytest.mark.parametrize("B,n,dim", [(3, 1000, 512), (1, 1, 64), (2, 8192, 128), (4, 37, 1024)])
+def test_zero_shot_scoring_kernel_vs_reference_arithmetic(gpu, fixture_cache, B, n, dim):
+    torch = pytest.importorskip("torch")
+    clip = gpu.Clip(fixtures.cached_model(fixture_cache, "tiny", "q8_0"), device=0)
+    rng = np.random.default_rng(B * 1000 + n)
+    img = (rng.standard_normal((B, dim)) * 0.3).astype(np.float32)
+    txt = (rng.standard_normal((n, dim)) * 0.3).astype(np.float32)
+    if n > 4:
+        txt[3] = txt[1]                                   # exact tie -> lower index first (stable sort)
+    d_img, d_txt = torch.from_numpy(img).cuda(), torch.from_numpy(txt).cuda()
+    d_sc = torch.empty((B, n), dtype=torch.float32, device="cuda")
+    d_ix = torch.empty((B, n), dtype=torch.int32, device="cuda")
+    assert gpu.lib().clip_amd_zero_shot_score_device(clip.ctx, d_img.data_ptr(), B, d_txt.data_ptr(), n, dim, d_sc.data_ptr(), d_ix.data_ptr())
+    clip.synchronize()
+    sc, ix = d_sc.cpu().numpy(), d_ix.cpu().numpy()
+    for b in range(B):
+        sims = np.array([ref.similarity(img[b], txt[j]) for j in range(n)], dtype=np.float32)   # sequential fp32 dot
+        s0, i0 = ref.softmax_with_sorting(sims)
+        np.testing.assert_allclose(sc[b], s0, rtol=2e-6, atol=1e-12)
+        same = ix[b] == i0
+        # indices may differ only where neighbouring scores are equal to the last bit (exp ulp differences)
+        assert np.all(same | np.isclose(sc[b], s0[np.argsort(np.argsort(-sc[b], kind="stable"))], rtol=2e-6)), b
+        assert sorted(ix[b]) == list(range(n))
+        if n > 4:
+            p1, p3 = int(np.where(ix[b] == 1)[0][0]), int(np.where(ix[b] == 3)[0][0])
+            assert p3 == p1 + 1
+
+
 def test_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
     """Small batches are captured into a hipGraph on the 2nd call with the same signature and replayed afterwards:
     eager (1st) == capture (2nd) == replay (3rd...), and a replay sees new pixel data written into the same buffers."""
