@@ -304,3 +304,62 @@ def test_reference_example_main_runs_unchanged_on_the_gpu_library(gpu, fixture_c
     ie = orc.image_batch_encode(orc.preprocess(pix)[None], normalize=True)[0]
     te = orc.text_encode(orc.tokenize(text), normalize=True)
     assert abs(float(m.group(1)) - ref.similarity(ie, te)) < 2e-3, (m.group(1), ref.similarity(ie, te))
+
+
+def test_reference_benchmark_program_runs_unchanged_on_the_gpu_library(gpu, fixture_cache, tmp_path):
+    """BASELINE config 5 flow: the reference's tests/benchmark.cpp compiled unchanged (oracle/_ref/ref_benchmark) walks a
+    class-per-directory image tree, encodes the class names and the images (batches of 4) through libclip.so on the GPU
+    and prints zero-shot acc@1 / acc@5 per class.  Expected numbers: the same composition through the Python binding."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_benchmark")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_benchmark not built (needs the reference tree)")
+    PIL = pytest.importorskip("PIL.Image")
+    p = fixtures.cached_model(fixture_cache, "b32", "f16")
+    rng = np.random.default_rng(11)
+    classes = ["cat", "dog", "red apple", "car", "tree", "house", "boat"]
+    root = tmp_path / "tree"
+    files = {}
+    for ci, c in enumerate(classes):
+        d = root / c
+        d.mkdir(parents=True)
+        files[c] = []
+        for k in range(4):
+            ny, nx = int(rng.integers(60, 300)), int(rng.integers(60, 300))
+            yy, xx = np.mgrid[0:ny, 0:nx]
+            img = np.clip(np.stack([(np.sin(xx / (5.0 + ci)) * 0.5 + 0.5) * 255, (np.cos(yy / (3.0 + k)) * 0.5 + 0.5) * 255,
+                                    (xx * (ci + 1) + yy * (k + 1)) % 256], -1) + rng.normal(0, 10, (ny, nx, 3)), 0, 255).astype(np.uint8)
+            f = str(d / ("img%d.%s" % (k, "png" if k % 2 else "jpg")))
+            PIL.fromarray(img).save(f)
+            files[c].append(f)
+    outf = str(tmp_path / "bench.txt")
+    out = subprocess.run([exe, p, str(root), "0", outf], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    report = open(outf).read()
+    got = {m.group(1).strip(): (float(m.group(2)), float(m.group(3))) for m in re.finditer(r"^\| (.{20}) \| ([0-9.]+) \| ([0-9.]+) \|$", report, re.M)}
+    assert set(classes) <= set(got), report
+    # expected: same composition via the binding (labels sorted like the std::map keys of benchmark.cpp)
+    clip = gpu.Clip(p, device=0)
+    L = gpu.lib()
+    order = sorted(classes)
+    txt = np.stack([np.asarray(clip.encode_text(clip.tokenize(c), normalize=True), dtype=np.float32) for c in order])
+    close_calls = 0
+    for li, c in enumerate(order):
+        a1 = a5 = 0
+        for f in files[c]:
+            u8 = L.clip_image_u8_make()
+            assert L.clip_image_load_from_file(os.fsencode(f), u8)
+            pix = np.ctypeslib.as_array(u8.contents.data, shape=(u8.contents.ny, u8.contents.nx, 3)).copy()
+            L.clip_image_u8_free(u8)
+            e = clip.encode_images(clip.preprocess(pix)[None], normalize=True)[0]
+            sims = np.array([ref.similarity(e, t) for t in txt], dtype=np.float32)
+            rank = list(np.argsort(-sims, kind="stable"))
+            srt = np.sort(sims)[::-1]
+            close_calls += int(np.min(np.abs(np.diff(srt))) < 1e-5)
+            a1 += rank[0] == li
+            a5 += li in rank[:5]
+        if close_calls == 0:
+            assert abs(got[c][0] - a1 / 4) < 1e-4 and abs(got[c][1] - a5 / 4) < 1e-4, (c, got[c], a1, a5, report)
+    assert "28 images encoded" in report and "7 texts encoded" in report, report
