@@ -19,7 +19,8 @@
 // Scores are never materialised in HBM (the reference materialises [T,T,n_head*B] f32).
 // Everything that indexes registers (key tiles NT, head-dim k-steps DKS, output d tiles DT) is a template
 // parameter and the MFMA chains are unconditional: padded keys are masked to -inf / multiplied by zero.
-// T <= 288 (all 224-px models and every text length); longer sequences are rejected by the launcher.
+// T <= 288 for every d_head in {32,64,80,96} (all 224-px models and every text length); T <= 592 for d_head <= 64
+// (ViT-L/14 at 336 px: T = 577, 154.6 KB of LDS); longer sequences are rejected by the launcher.
 
 #include "kernels.h"
 
@@ -44,9 +45,14 @@ struct AttnParams {
 // NT  = number of 16-key tiles (>= ceil(max_len/16)); DKS = 32-wide k-steps over the head dim (dh <= 32*DKS);
 // DT = dh/16 output tiles.
 template <int NT, int DKS, int DT>
-__global__ void __launch_bounds__(256) attn_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, (NT > 18 ? 1 : 2)) attn_kernel(const AttnParams p) {
     constexpr int DKP = DKS * 32;
-    constexpr int KSTRIDE = DKP + 8;                 // halfs per K row  (+16 B pad: spreads ds_read_b128 over banks)
+    // Long sequences (NT > 18: 336-px models, T = 577) only fit the 160 KB LDS without the row padding: K rows are then
+    // exactly 128 B with the 16-byte chunks XOR-swizzled by (key & 7) instead (same conflict-free ds_read_b128 pattern
+    // as the GEMM tiles); needs DKP == 64.
+    constexpr bool SWZ = NT > 18;
+    static_assert(!SWZ || DKP == 64, "swizzled K layout is for d_head <= 64");
+    constexpr int KSTRIDE = SWZ ? DKP : DKP + 8;     // halfs per K row  (+16 B pad: spreads ds_read_b128 over banks)
     constexpr int NPR = (NT + 1) / 2;                // key-tile pairs = K=32 slices of the P.V contraction
     constexpr int VSTRIDE = NPR * 32 + 8;            // halfs per V^T row; (VSTRIDE/2) = 4*odd -> conflict-free ds_read_b64
     constexpr int DH = DT * 16;
@@ -77,7 +83,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnParams p) {
             const int key = it / KCH, c = it % KCH;
             u32x4 v = (u32x4){0u, 0u, 0u, 0u};
             if (key < len && c < DCH) v = *(const u32x4 *)(Kg + (size_t)key * ld + c * 8);
-            *(u32x4 *)(Ks + key * KSTRIDE + c * 8) = v;
+            *(u32x4 *)(Ks + key * KSTRIDE + (SWZ ? (c ^ (key & 7)) : c) * 8) = v;
         }
     }
     // ---- stage V transposed: Vt[d][key]; two keys per thread so every LDS store is a full dword ----
@@ -121,9 +127,13 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnParams p) {
             s[kt] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < DKS; kk++) {
-                const h8 kf = *(const h8 *)(Ks + (kt * 16 + fq) * KSTRIDE + kk * 32 + fg * 8);
+                const int kch = kk * 4 + fg;
+                const h8 kf = *(const h8 *)(Ks + (kt * 16 + fq) * KSTRIDE + (SWZ ? (kch ^ (fq & 7)) : kch) * 8);
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);
             }
+            // keep at most 4 key tiles (8 fragment reads) in flight: fully hoisted, the reads of all NT tiles cost
+            // 4*2*NT VGPRs (NT = 18: 488 registers, one workgroup per CU)
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- mask + row max.  lane holds query fq, keys kt*16 + fg*4 + r ----
         const int kmax = p.causal ? (qrow < len - 1 ? qrow : len - 1) : len - 1;   // last visible key
@@ -177,6 +187,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnParams p) {
                 vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[dt], 0, 0, 0);
             }
+            if ((pr & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- normalise rows and store.  O layout: row (query) = fg*4 + r, col (d) = fq ----
         float invr[4];
@@ -196,7 +207,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnParams p) {
 
 template <int NT, int DKS, int DT>
 void launch_inst(const AttnParams & p, int nseq, hipStream_t stream) {
-    constexpr size_t smem = ((size_t)NT * 16 * (DKS * 32 + 8) + (size_t)DT * 16 * (((NT + 1) / 2) * 32 + 8)) * sizeof(half_t);
+    constexpr size_t smem = ((size_t)NT * 16 * (DKS * 32 + (NT > 18 ? 0 : 8)) + (size_t)DT * 16 * (((NT + 1) / 2) * 32 + 8)) * sizeof(half_t);
+    static_assert(smem <= 160 * 1024, "attention tile does not fit the LDS");
     static bool attr_set = false;   // dynamic LDS above 64 KB needs the opt-in once per kernel
     if (smem > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)attn_kernel<NT, DKS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -217,7 +229,10 @@ bool launch_nt(const AttnParams & p, int nseq, int nt, hipStream_t stream) {
     else if (nt <= 14) launch_inst<14, DKS, DT>(p, nseq, stream);
     else if (nt <= 17) launch_inst<17, DKS, DT>(p, nseq, stream);
     else if (nt <= 18) launch_inst<18, DKS, DT>(p, nseq, stream);
-    else return false;
+    else if constexpr (DKS == 2) {
+        if (nt <= 37) launch_inst<37, DKS, DT>(p, nseq, stream);   // 336-px ViT-L/14: T = 577
+        else return false;
+    } else return false;
     return true;
 }
 
@@ -227,7 +242,7 @@ bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform,
                       int h, int n_head, bool causal, hipStream_t stream) {
     if (nseq <= 0) return true;
     const int dh = h / n_head;
-    if (max_len > 288 || max_len <= 0) return false;
+    if (max_len > 592 || max_len <= 0) return false;
     AttnParams p;
     p.qkv = qkv;
     p.out = out;

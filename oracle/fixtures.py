@@ -20,6 +20,8 @@ CONFIGS = {
     # name: vision(S,P,h,L,nh,ff,proj)  text(h,L,nh,ff,proj,npos)
     "tiny": dict(v=dict(S=32, P=8, h=64, L=2, nh=2, ff=128, proj=32), t=dict(h=64, L=2, nh=2, ff=128, proj=32, npos=77)),
     "tiny14": dict(v=dict(S=28, P=14, h=128, L=2, nh=2, ff=256, proj=64), t=dict(h=64, L=2, nh=2, ff=128, proj=64, npos=77)),
+    # 336-px geometry of ViT-L/14@336 (T = 24*24 + 1 = 577 tokens, d_head 64) on a small width: long-sequence attention path
+    "tiny336": dict(v=dict(S=336, P=14, h=128, L=2, nh=2, ff=256, proj=64), t=dict(h=64, L=2, nh=2, ff=128, proj=64, npos=77)),
     "b32": dict(v=dict(S=224, P=32, h=768, L=12, nh=12, ff=3072, proj=512), t=dict(h=512, L=12, nh=8, ff=2048, proj=512, npos=77)),
     "b16": dict(v=dict(S=224, P=16, h=768, L=12, nh=12, ff=3072, proj=512), t=dict(h=512, L=12, nh=8, ff=2048, proj=512, npos=77)),
     "l14": dict(v=dict(S=224, P=14, h=1024, L=24, nh=16, ff=4096, proj=768), t=dict(h=768, L=12, nh=12, ff=3072, proj=768, npos=77)),

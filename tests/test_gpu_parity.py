@@ -142,6 +142,17 @@ def test_full_size_properties_b32_q4_0_batch256(gpu, fixture_cache):
     assert np.all(one_minus_cos(sub32, full[:32]) <= 1e-6)
 
 
+@pytest.mark.parametrize("ftype", ["f16", "q4_0"])
+def test_336px_geometry_t577(gpu, fixture_cache, ftype):
+    """ViT-L/14@336 geometry (T = 577 tokens, d_head 64): the long-sequence attention instantiation (swizzled K, 155 KB LDS)."""
+    p = fixtures.cached_model(fixture_cache, "tiny336", ftype, text=False, vision=True)
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(3, 336, seed=15)
+    got = clip.encode_images(imgs)
+    want = orc.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL)
+    assert np.all(one_minus_cos(got, want) <= TOL[ftype]), one_minus_cos(got, want)
+
+
 def test_vit_l14_f16_shapes(gpu, fixture_cache):
     """BASELINE config 3 shapes (ViT-L/14 f16, T=257, d_head 64): 2 images vs the oracle."""
     p = fixtures.cached_model(fixture_cache, "l14", "f16", text=False, vision=True)
