@@ -383,5 +383,11 @@ class Clip:
             pass
 
 
+def gguf_inspect(path):
+    """(kv dict, [(tensor name, dims, ggml type)]) of a GGUF file (metadata only; see convert_hf_to_gguf.py)."""
+    from .convert_hf_to_gguf import gguf_inspect as _gi
+    return _gi(path)
+
+
 def quantize(fname_inp, fname_out, itype):
     return bool(lib().clip_model_quantize(os.fsencode(fname_inp), os.fsencode(fname_out), int(itype)))
