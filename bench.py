@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--texts", type=int, default=-1, help="texts per GPU per step (default = batch)")
     ap.add_argument("--vision-only", action="store_true", help="vision tower only (implies --texts 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=32, help="images (and texts) of the workload timed on the CPU oracle: ~20-30 core-seconds")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--preheat", type=float, default=1.0,
                     help="seconds of untimed stepping BEFORE the W warm-up steps (a cold MI355X needs ~0.5 s of load to reach its "
@@ -217,7 +217,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "CLIP ViT-%s %s two-tower: %d images (224x224, vision tower) + %d texts (1-75 tokens, text tower) per GPU per step, inputs resident in HBM, RCCL all-gather of final embeddings when N>1"
                                    % (args.model.upper(), args.ftype, args.batch, n_texts),
-                       "model": args.model, "ftype": args.ftype, "images_per_gpu": args.batch, "texts_per_gpu": n_texts,
+                       "weights": "%s %s GGUF, seeded synthetic" % (args.model, args.ftype), "images_per_gpu": args.batch, "texts_per_gpu": n_texts,
                        "text_tokens_per_gpu": int(offsets[-1]), "parallelism": "dp%d" % N},
             "images_per_s_per_gpu": round(img_rate, 1), "texts_per_s_per_gpu": round(txt_rate, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,

@@ -9,12 +9,13 @@ echo "== kernels tests" ; timeout 900 python -m pytest tests/test_gpu_kernels.py
 echo "== parity tests" ; timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -15 | tee gpurun_out/${TAG}_parity.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
 echo "== bench" ; timeout 900 python bench.py --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -2 | cut -c1-3000 | tee gpurun_out/${TAG}_bench.log
-echo "== rocprof kernel trace" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
+echo "== rocprof kernel trace" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 10 --warmup 3 --preheat 0.3 --no-cpu-baseline --no-roofline > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
 for f in $(find /tmp/prof_${TAG} -name "*kernel_stats*.csv"); do grep -v "at::native\|__amd_rocclr" $f | cut -c1-400 > gpurun_out/${TAG}_kernel_stats.csv; done
 head -8 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200
 echo "== rocprof PMC (HBM traffic)"
-for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$set -o pmc -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_${TAG}_$set.log 2>&1)
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
+  n=$(echo $set | cut -d' ' -f1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$n -o pmc -- python "${GRAFT_REPO_ROOT:-/root/repo}/bench.py" --steps 3 --warmup 1 --preheat 0 --no-cpu-baseline --no-roofline > /tmp/pmc_${TAG}_$n.log 2>&1)
 done
 python - <<PY | tee gpurun_out/${TAG}_pmc_traffic.txt
 import csv, glob, collections, json
@@ -32,4 +33,11 @@ for k in acc:
     out[k] = {"fetch_kb_raw": fs, "write_kb_raw": ws, "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0, "launches": cnt[(k, "FETCH_SIZE")]}
     print("%-60s FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  -> HBM bytes/launch (fetch x2) %.3e  [%d launches]" % (k[:60], fs, ws, out[k]["hbm_bytes_per_launch"], cnt[(k, "FETCH_SIZE")]))
 json.dump(out, open("gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
+print("-- MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs; 16 cycles per v_mfma_f32_16x16x32_f16; GRBM_GUI_ACTIVE = GPU-active cycles of the dispatch)")
+for k in acc:
+    a = {c: acc[k][c] / max(1, cnt[(k, c)]) for c in acc[k]}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE", 0) > 0:
+        print("%-60s MFMA_BUSY %.3e  INSTS_MFMA %.3e  BUSY_CU %.3e  GUI_ACTIVE %.3e  -> busy/(GUI_ACTIVE*1024 SIMDs) = %.3f" % (
+            k[:60], a["SQ_VALU_MFMA_BUSY_CYCLES"], a.get("SQ_INSTS_MFMA", 0), a.get("SQ_BUSY_CU_CYCLES", 0), a["GRBM_GUI_ACTIVE"],
+            a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] * 1024.0)))
 PY
