@@ -73,7 +73,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
         return;
     }
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
-    const double by = weight_bytes(p.W) + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : 4);
+    const double by = weight_bytes(p.W) + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4);   // fused residual: read + write
     // tag = kernel instantiation (matches the rocprofv3 kernel name gemm_dma_kernel<WT, BM, BN, EPI>) + role
     const int tile = gemm_tile_for(p.M, p.W.N);
     char fam[96];

@@ -37,7 +37,7 @@ print("-- MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs; 16 cycles p
 for k in acc:
     a = {c: acc[k][c] / max(1, cnt[(k, c)]) for c in acc[k]}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE", 0) > 0:
-        print("%-60s MFMA_BUSY %.3e  INSTS_MFMA %.3e  BUSY_CU %.3e  GUI_ACTIVE %.3e  -> busy/(GUI_ACTIVE*1024 SIMDs) = %.3f" % (
+        print("%-60s MFMA_BUSY %.3e  INSTS_MFMA %.3e  BUSY_CU %.3e  GUI_ACTIVE %.3e  -> MFMA-busy fraction = busy / (GUI_ACTIVE/8 XCDs x 1024 SIMDs) = %.3f" % (
             k[:60], a["SQ_VALU_MFMA_BUSY_CYCLES"], a.get("SQ_INSTS_MFMA", 0), a.get("SQ_BUSY_CU_CYCLES", 0), a["GRBM_GUI_ACTIVE"],
-            a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] * 1024.0)))
+            a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)))
 PY
