@@ -209,11 +209,8 @@ template <int NT, int DKS, int DT>
 void launch_inst(const AttnParams & p, int nseq, hipStream_t stream) {
     constexpr size_t smem = ((size_t)NT * 16 * (DKS * 32 + (NT > 18 ? 0 : 8)) + (size_t)DT * 16 * (((NT + 1) / 2) * 32 + 8)) * sizeof(half_t);
     static_assert(smem <= 160 * 1024, "attention tile does not fit the LDS");
-    static bool attr_set = false;   // dynamic LDS above 64 KB needs the opt-in once per kernel
-    if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)attn_kernel<NT, DKS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (smem > 64 * 1024) opt_in_dynamic_lds(attn_kernel<NT, DKS, DT>, smem, lds_ok);
     hipLaunchKernelGGL((attn_kernel<NT, DKS, DT>), dim3(nseq * p.n_head), dim3(256), smem, stream, p);
 }
 

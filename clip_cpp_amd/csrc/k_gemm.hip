@@ -417,11 +417,8 @@ template <int WT, int BM, int BN, int EPI>
 void launch_dma(const GemmParams & p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + BN - 1) / BN;
     constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
-    static bool attr_set = false;   // dynamic LDS above 64 KB needs the opt-in once per kernel
-    if (smem > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)gemm_dma_kernel<WT, BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (smem > 64 * 1024) opt_in_dynamic_lds(gemm_dma_kernel<WT, BM, BN, EPI>, smem, lds_ok);
     int grid = tiles_m * tiles_n;
     if (BM == 64) grid *= p.ksplit;   // p.ksplit validated by launch_gemm
     hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(grid), dim3(NTHREADS), smem, stream, p);

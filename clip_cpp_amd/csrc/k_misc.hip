@@ -326,11 +326,8 @@ bool launch_zero_shot(const float * img, int B, const float * txt, int n, int di
     while (npad < n) npad <<= 1;
     if (npad > 8192) return false;
     const size_t smem = (size_t)npad * 8 + (size_t)dim * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)zero_shot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 4096 * 4);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    opt_in_dynamic_lds(zero_shot_kernel, 8192 * 8 + 4096 * 4, lds_ok);
     if (dim > 4096) return false;
     hipLaunchKernelGGL(zero_shot_kernel, dim3(B), dim3(256), smem, stream, img, txt, n, dim, npad, scores, indices);
     return true;

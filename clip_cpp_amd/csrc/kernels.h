@@ -11,6 +11,18 @@ namespace clipamd {
 
 typedef _Float16 half_t;
 
+// Kernels with more than 64 KB of dynamic LDS need hipFuncSetAttribute once PER DEVICE (a process may hold contexts on
+// several GPUs): `done` is a per-kernel static bitmask of device ordinals already configured.
+template <typename K>
+inline void opt_in_dynamic_lds(K kernel, size_t bytes, unsigned long long & done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return;
+    (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done |= bit;
+}
+
 // Device weight formats (repacked from the ggml block layout at load time, see model.cpp).
 enum WType : int { W_F16 = 0, W_Q4_0 = 1, W_Q4_1 = 2, W_Q5_0 = 3, W_Q5_1 = 4, W_Q8_0 = 5 };
 

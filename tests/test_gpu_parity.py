@@ -164,6 +164,19 @@ def test_vit_l14_f16_shapes(gpu, fixture_cache):
     assert np.all(d <= 1e-4), d
 
 
+@pytest.mark.parametrize("config,ftype", [("l14", "q5_1"), ("h14", "q8_0")])
+def test_large_model_shapes_quantised(gpu, fixture_cache, config, ftype):
+    """BASELINE config 4 (ViT-L/14 q5_1) and config 5 (ViT-H/14 q8_0: d_head 80, 32 layers) shapes: one image vs the oracle,
+    plus batch consistency (the same image inside a batch of 3)."""
+    p = fixtures.cached_model(fixture_cache, config, ftype, text=False, vision=True)
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(3, 224, seed=31)
+    got = clip.encode_images(imgs)
+    want = orc.image_batch_encode(imgs[:1], mode=ref.MODE_FAITHFUL)
+    assert one_minus_cos(got[:1], want)[0] <= TOL[ftype], one_minus_cos(got[:1], want)
+    assert one_minus_cos(clip.encode_images(imgs[:1]), got[:1])[0] <= 1e-6
+
+
 def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
     torch = pytest.importorskip("torch")
     p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
