@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclip.so")
+LIB_PATH = os.environ.get("CLIP_AMD_LIB") or os.path.join(_HERE, "libclip.so")   # CLIP_AMD_LIB: kernel A/B builds (scripts/build_variant.sh)
 
 
 class ClipTextHparams(C.Structure):  # reference clip.h:14-23

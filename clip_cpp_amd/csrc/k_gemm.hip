@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         const half_t * xs = Xs + (buf_) * BM * BK;                                             \
         const half_t * ws = Ws + (buf_) * BN * BK;                                             \
         h8 xf[2][TM], wf[2][TN];                                                               \
+        COMPUTE_PRIO_BEGIN                                                                     \
         _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
             _Pragma("unroll") for (int a = 0; a < TN; a++)                                     \
                 wf[kk][a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
@@ -317,13 +318,31 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
                 _Pragma("unroll") for (int b = 0; b < TM; b++)                                 \
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][b], acc[a][b], 0, 0, 0); \
         /* schedule: the TN+TM reads of slice 0, then slice-0 MFMAs with the slice-1 reads slotted in, then slice-1 MFMAs */ \
+        COMPUTE_SCHED                                                                          \
+        COMPUTE_PRIO_END                                                                       \
+    }
+#ifdef CLIPAMD_PRIO
+#define COMPUTE_PRIO_BEGIN __builtin_amdgcn_s_setprio(CLIPAMD_PRIO);
+#define COMPUTE_PRIO_END __builtin_amdgcn_s_setprio(0);
+#else
+#define COMPUTE_PRIO_BEGIN
+#define COMPUTE_PRIO_END
+#endif
+#if !defined(CLIPAMD_SCHED) || CLIPAMD_SCHED == 0
+#define COMPUTE_SCHED                                                                          \
         __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                               \
         _Pragma("unroll") for (int i = 0; i < TN + TM; i++) {                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, (TN * TM) / (TN + TM), 0);             \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
         }                                                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0); \
-    }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0);
+#elif CLIPAMD_SCHED == 1
+#define COMPUTE_SCHED __builtin_amdgcn_iglp_opt(0);
+#elif CLIPAMD_SCHED == 2
+#define COMPUTE_SCHED __builtin_amdgcn_iglp_opt(1);
+#else
+#define COMPUTE_SCHED
+#endif
 
     DMA_TILE(0, 0);
     LOAD_B(B0, 0);
@@ -362,6 +381,9 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
 #undef LOAD_B
 #undef STORE_B
 #undef COMPUTE
+#undef COMPUTE_SCHED
+#undef COMPUTE_PRIO_BEGIN
+#undef COMPUTE_PRIO_END
     asm volatile("" ::: "memory");
     if constexpr (SK) {
         if (ksplit > 1) {
