@@ -536,9 +536,9 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
     launch_f32_to_f16((const float *)dx32.p, (int)K, (half_t *)dx16.p, Kpad, (int)M, (int)K, Kpad, s);
     GemmParams p;
     p.A = (const half_t *)dx16.p; p.lda = Kpad; p.M = (int)M; p.W = W; p.bias = bias ? (const float *)dbias.p : nullptr; p.ldc = (int)N;
-    DBuf skw((size_t)16 << 20), skc(4096 * 4);   // split-K workspace + ticket counters (as load.cpp gives the ctx)
+    DBuf skw((size_t)64 << 20), skc(4096 * 4);   // split-K workspace + ticket counters (as load.cpp gives the ctx)
     (void)hipMemset(skc.p, 0, 4096 * 4);
-    p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)4 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
+    p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)16 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
     int epi = EPI_F32;
     switch (epilogue) {
     case 0: epi = EPI_F32; p.out = dout32.p; break;
@@ -588,9 +588,9 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     GemmParams p;
     p.A = (const half_t *)dx.p; p.lda = Kpad; p.M = (int)M; p.W = W; p.bias = (const float *)dbias.p; p.ldc = (int)N; p.out = dout.p;
     p.resid = (const float *)dout.p; p.qcols = 0;
-    DBuf skw((size_t)16 << 20), skc(4096 * 4);
+    DBuf skw((size_t)64 << 20), skc(4096 * 4);
     (void)hipMemset(skc.p, 0, 4096 * 4);
-    p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)4 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
+    p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)16 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
     p.debug = epilogue >> 8;   // ablation switches in the high bits (tuning only)
     epilogue &= 0xFF;
     hipEvent_t a, b;

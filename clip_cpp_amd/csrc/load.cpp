@@ -385,8 +385,8 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     { const char * g = getenv("CLIP_AMD_GRAPHS"); if (g && g[0] == '0') ctx->graphs_enabled = false; }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     ctx->stream = ctx->own_stream;
-    {   // split-K workspace (small-M GEMMs): 16 MB of partial tiles + 4096 ticket counters
-        const size_t nfl = (size_t)4 << 20;
+    {   // split-K workspace (small-M GEMMs): 64 MB of partial tiles + 4096 ticket counters
+        const size_t nfl = (size_t)16 << 20;
         void * w = nullptr, * c = nullptr;
         if (hipMalloc(&w, nfl * sizeof(float)) != hipSuccess || hipMalloc(&c, 4096 * sizeof(unsigned)) != hipSuccess || hipMemset(c, 0, 4096 * sizeof(unsigned)) != hipSuccess)
             return fail("hipMalloc (split-K workspace) failed");
