@@ -350,20 +350,8 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
     STORE_B(B0, 0);
     __syncthreads();
     int kt = 0;
-    if (p.debug == 0) {
-    for (; kt + 1 < nk; kt += 2) {
-        DMA_TILE(1, kt + 1);
-        { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
-        COMPUTE(0);
-        STORE_B(B1, 1);
-        __syncthreads();
-        { const int t2 = kt + 2 < last ? kt + 2 : last; DMA_TILE(0, t2); }
-        { const int t3 = kt + 3 < last ? kt + 3 : last; LOAD_B(B1, t3); }
-        COMPUTE(1);
-        STORE_B(B0, 0);
-        __syncthreads();
-    }
-    } else {   // ablation copy of the loop (kernel tuning only; results are garbage)
+#ifdef CLIPAMD_ABLATION   // kernel-tuning builds only (scripts/build_variant.sh abl -DCLIPAMD_ABLATION): p.debug switches parts of the loop off
+    if (p.debug != 0) {
     const bool noload = p.debug & 1, nomfma = p.debug & 2, nostore = p.debug & 4;
     for (; kt + 1 < nk; kt += 2) {
         if (!noload) { DMA_TILE(1, kt + 1); const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
@@ -375,6 +363,19 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         if (!nostore) { STORE_B(B0, 0); }
         __syncthreads();
     }
+    } else
+#endif
+    for (; kt + 1 < nk; kt += 2) {
+        DMA_TILE(1, kt + 1);
+        { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
+        COMPUTE(0);
+        STORE_B(B1, 1);
+        __syncthreads();
+        { const int t2 = kt + 2 < last ? kt + 2 : last; DMA_TILE(0, t2); }
+        { const int t3 = kt + 3 < last ? kt + 3 : last; LOAD_B(B1, t3); }
+        COMPUTE(1);
+        STORE_B(B0, 0);
+        __syncthreads();
     }
     if (kt < nk) COMPUTE(0);
 #undef DMA_TILE

@@ -74,7 +74,7 @@ struct GemmParams {
     unsigned * sk_cnt = nullptr;
     int sk_cnt_n = 0;
     int ksplit = 1;
-    int debug = 0;   // ablation switches for kernel tuning (scripts/gemm_bench.py): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
+    int debug = 0;   // ablation switches, honoured only by -DCLIPAMD_ABLATION tuning builds (scripts/build_variant.sh): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
 };
 
 // tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64)
