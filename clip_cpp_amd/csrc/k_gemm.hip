@@ -344,6 +344,51 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
 #define COMPUTE_SCHED
 #endif
 
+// Rotated K loop (used for f16 weight files: measured +1-7 % there, but -5-25 % with the dequantisation in the loop): the barrier sits in the MIDDLE of a step's MFMA chain.  After the barrier a wave first issues the
+// slice-0 fragment reads of the new step and then runs the slice-1 MFMAs of the PREVIOUS step (operands already in
+// registers), so the LDS round trip that follows every barrier is covered by 2*... MFMAs instead of being exposed; the
+// dequant + ds_write of the next weight tile comes before the slice-0 MFMAs so its lgkmcnt drain overlaps them too.
+    h8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+#pragma unroll
+    for (int a = 0; a < TN; a++) wf1[a] = (h8)(_Float16)0;
+#pragma unroll
+    for (int b = 0; b < TM; b++) xf1[b] = (h8)(_Float16)0;
+#define READ0(buf_)                                                                            \
+    {                                                                                          \
+        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
+        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
+        _Pragma("unroll") for (int a = 0; a < TN; a++) wf0[a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, fgrp)); \
+        _Pragma("unroll") for (int b = 0; b < TM; b++) xf0[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, fgrp)); \
+    }
+#define MMA1()                                                                                 \
+    {                                                                                          \
+        _Pragma("unroll") for (int a = 0; a < TN; a++)                                         \
+            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[a], xf1[b], acc[a][b], 0, 0, 0); \
+    }
+#define READ0_MMA1(buf_)                                                                       \
+    {                                                                                          \
+        READ0(buf_)                                                                            \
+        MMA1()                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);                               \
+    }
+#define MMA0_READ1(buf_)                                                                       \
+    {                                                                                          \
+        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
+        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
+        _Pragma("unroll") for (int a = 0; a < TN; a++) wf1[a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, 4 + fgrp)); \
+        _Pragma("unroll") for (int b = 0; b < TM; b++) xf1[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, 4 + fgrp)); \
+        _Pragma("unroll") for (int a = 0; a < TN; a++)                                         \
+            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[a], xf0[b], acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TN + TM; i++) {                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, (TN * TM) / (TN + TM), 0);             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+        }                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0); \
+    }
+
     DMA_TILE(0, 0);
     LOAD_B(B0, 0);
     { const int t1 = last < 1 ? last : 1; LOAD_B(B1, t1); }
@@ -365,6 +410,24 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
     }
     } else
 #endif
+    if constexpr (WT == W_F16) {
+    for (; kt + 1 < nk; kt += 2) {
+        READ0_MMA1(0);
+        DMA_TILE(1, kt + 1);
+        { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
+        STORE_B(B1, 1);
+        MMA0_READ1(0);
+        __syncthreads();
+        READ0_MMA1(1);
+        { const int t2 = kt + 2 < last ? kt + 2 : last; DMA_TILE(0, t2); }
+        { const int t3 = kt + 3 < last ? kt + 3 : last; LOAD_B(B1, t3); }
+        STORE_B(B0, 0);
+        MMA0_READ1(1);
+        __syncthreads();
+    }
+    if (kt < nk) { READ0_MMA1(0); MMA0_READ1(0); }
+    MMA1();
+    } else {
     for (; kt + 1 < nk; kt += 2) {
         DMA_TILE(1, kt + 1);
         { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
@@ -378,6 +441,11 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         __syncthreads();
     }
     if (kt < nk) COMPUTE(0);
+    }
+#undef READ0
+#undef MMA1
+#undef READ0_MMA1
+#undef MMA0_READ1
 #undef DMA_TILE
 #undef LOAD_B
 #undef STORE_B
