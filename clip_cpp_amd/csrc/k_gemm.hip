@@ -22,13 +22,19 @@
 //   * two LDS buffers, one barrier per K-step; the barrier's vmcnt(0) is what lands the DMA, so nothing inside a
 //     K-step waits on memory; every prefetch is unconditional (clamped tile index) so hipcc's s_waitcnt counting
 //     stays exact;
+//   * the K-step of the big tiles (BM >= 128) is written as an explicit instruction interleave: groups of two MFMAs
+//     fenced by sched_barrier(0), with the fragment reads, the LDS-DMA pieces of the next tile and the dequantisation
+//     + ds_write of the next weight tile placed between the groups in source order (STEP_ILV), so that VALU / LDS /
+//     VMEM issue runs under the matrix pipe; hipcc's own scheduling (plain, sched_group_barrier pipelines,
+//     iglp_opt) clumps that work after the MFMA chain (+4-7 % from the explicit interleave, profiles/);
 //   * workgroup -> tile mapping: XCD-contiguous chunks, n fastest, so the workgroups that share an activation
 //     row-panel run back to back on one XCD/L2 (measured: L2 hit rate 32 % -> 85 %, HBM traffic = algorithmic).
 //
 // Roofline: compute (MFMA fp16, 2.5 PFLOP/s dense) for M >= ~256; HBM (weight bytes) for M <= 64.
-// Measured (r01, MI355X): 550-700 TFLOP/s on the ViT-B/32 / L/14 shapes; ablation (profiles/): the ds_read+MFMA
-// loop alone sustains ~1.08 PFLOP/s and the staging alone ~0.9 PFLOP/s-equivalent: the 2-barrier 128^2 structure
-// is the limit, the next step is a 256-wide 8-wave multi-phase pipeline.
+// Measured (r01, MI355X): 0.65-0.93 PFLOP/s on the ViT-B/32 / L/14 shapes (hipBLASLt, plain f16, no epilogue:
+// 0.88-1.23).  Micro-benchmarks (scripts/*_bench.hip, profiles/): the matrix pipe alone 2.2-2.46 PFLOP/s, the bare
+// LDS->register->MFMA loop of this tile structure 1.5-1.8, tile streaming L2->LDS ~20 TB/s and not latency-bound.
+// The remaining step is a 256-wide register tile with a hand-scheduled (assembly) K loop.
 
 #include "kernels.h"
 
@@ -306,7 +312,6 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         const half_t * xs = Xs + (buf_) * BM * BK;                                             \
         const half_t * ws = Ws + (buf_) * BN * BK;                                             \
         h8 xf[2][TM], wf[2][TN];                                                               \
-        COMPUTE_PRIO_BEGIN                                                                     \
         _Pragma("unroll") for (int kk = 0; kk < 2; kk++) {                                     \
             _Pragma("unroll") for (int a = 0; a < TN; a++)                                     \
                 wf[kk][a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fgrp)); \
@@ -319,16 +324,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][a], xf[kk][b], acc[a][b], 0, 0, 0); \
         /* schedule: the TN+TM reads of slice 0, then slice-0 MFMAs with the slice-1 reads slotted in, then slice-1 MFMAs */ \
         COMPUTE_SCHED                                                                          \
-        COMPUTE_PRIO_END                                                                       \
     }
-#ifdef CLIPAMD_PRIO
-#define COMPUTE_PRIO_BEGIN __builtin_amdgcn_s_setprio(CLIPAMD_PRIO);
-#define COMPUTE_PRIO_END __builtin_amdgcn_s_setprio(0);
-#else
-#define COMPUTE_PRIO_BEGIN
-#define COMPUTE_PRIO_END
-#endif
-#if !defined(CLIPAMD_SCHED) || CLIPAMD_SCHED == 0
 #define COMPUTE_SCHED                                                                          \
         __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                               \
         _Pragma("unroll") for (int i = 0; i < TN + TM; i++) {                                  \
@@ -336,57 +332,61 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
         }                                                                                      \
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0);
-#elif CLIPAMD_SCHED == 1
-#define COMPUTE_SCHED __builtin_amdgcn_iglp_opt(0);
-#elif CLIPAMD_SCHED == 2
-#define COMPUTE_SCHED __builtin_amdgcn_iglp_opt(1);
-#else
-#define COMPUTE_SCHED
-#endif
 
-// Rotated K loop (used for f16 weight files: measured +1-7 % there, but -5-25 % with the dequantisation in the loop): the barrier sits in the MIDDLE of a step's MFMA chain.  After the barrier a wave first issues the
-// slice-0 fragment reads of the new step and then runs the slice-1 MFMAs of the PREVIOUS step (operands already in
-// registers), so the LDS round trip that follows every barrier is covered by 2*... MFMAs instead of being exposed; the
-// dequant + ds_write of the next weight tile comes before the slice-0 MFMAs so its lgkmcnt drain overlaps them too.
-    h8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-#pragma unroll
-    for (int a = 0; a < TN; a++) wf1[a] = (h8)(_Float16)0;
-#pragma unroll
-    for (int b = 0; b < TM; b++) xf1[b] = (h8)(_Float16)0;
-#define READ0(buf_)                                                                            \
+// Interleaved K-step (BM >= 128, BN = 128): the step is cut into groups of GS MFMAs fenced by
+// sched_barrier(0), and the other work is placed BETWEEN the groups in source order — slice-1 fragment reads and the
+// LDS-DMA pieces of the next activation tile among the slice-0 MFMAs, the dequantisation + ds_write of the next weight
+// tile (one 8-weight word per slot) among the slice-1 MFMAs — so VALU / LDS / VMEM issue runs under the matrix pipe
+// instead of after it.
+    constexpr bool ILV = BM >= 128 && BN == 128;
+    constexpr int NPC = XPW + (WT == W_F16 ? WPW : 0);   // LDS-DMA pieces per wave per K-step
+    constexpr int NM = TN * TM, GS = 2, NG = (NM + GS - 1) / GS;
+#define FRAG(base_, row_, c_) (*(const h8 *)((base_) + lds_off((row_), (c_))))
+#define STEP_ILV(buf_, dkt_, BL, lkt_, BS)                                                     \
     {                                                                                          \
         const half_t * xs = Xs + (buf_) * BM * BK;                                             \
         const half_t * ws = Ws + (buf_) * BN * BK;                                             \
-        _Pragma("unroll") for (int a = 0; a < TN; a++) wf0[a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, fgrp)); \
-        _Pragma("unroll") for (int b = 0; b < TM; b++) xf0[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, fgrp)); \
-    }
-#define MMA1()                                                                                 \
-    {                                                                                          \
-        _Pragma("unroll") for (int a = 0; a < TN; a++)                                         \
-            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[a], xf1[b], acc[a][b], 0, 0, 0); \
-    }
-#define READ0_MMA1(buf_)                                                                       \
-    {                                                                                          \
-        READ0(buf_)                                                                            \
-        MMA1()                                                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, TN * TM, 0);                               \
-    }
-#define MMA0_READ1(buf_)                                                                       \
-    {                                                                                          \
-        const half_t * xs = Xs + (buf_) * BM * BK;                                             \
-        const half_t * ws = Ws + (buf_) * BN * BK;                                             \
-        _Pragma("unroll") for (int a = 0; a < TN; a++) wf1[a] = *(const h8 *)(ws + lds_off(wn * (BN / 2) + a * 16 + frow, 4 + fgrp)); \
-        _Pragma("unroll") for (int b = 0; b < TM; b++) xf1[b] = *(const h8 *)(xs + lds_off(wm * (BM / 2) + b * 16 + frow, 4 + fgrp)); \
-        _Pragma("unroll") for (int a = 0; a < TN; a++)                                         \
-            _Pragma("unroll") for (int b = 0; b < TM; b++)                                     \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[a], xf0[b], acc[a][b], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < TN + TM; i++) {                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, (TN * TM) / (TN + TM), 0);             \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+        half_t * wrow_ = Ws + ((buf_) ^ 1) * BN * BK + bnl * BK;                               \
+        h8 xf[2][TM], wf[2][TN];                                                               \
+        _Pragma("unroll") for (int a = 0; a < TN; a++) wf[0][a] = FRAG(ws, wn * (BN / 2) + a * 16 + frow, fgrp); \
+        _Pragma("unroll") for (int b = 0; b < TM; b++) xf[0][b] = FRAG(xs, wm * (BM / 2) + b * 16 + frow, fgrp); \
+        LOAD_B(BL, lkt_);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int g = 0; g < NG; g++) {                                       \
+            _Pragma("unroll") for (int i = 0; i < GS; i++) {                                   \
+                const int idx = g * GS + i;                                                    \
+                if (idx < NM) acc[idx / TM][idx % TM] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][idx / TM], xf[0][idx % TM], acc[idx / TM][idx % TM], 0, 0, 0); \
+            }                                                                                  \
+            if (g < TN) wf[1][g < TN ? g : 0] = FRAG(ws, wn * (BN / 2) + g * 16 + frow, 4 + fgrp); \
+            else if (g < TN + TM) xf[1][g < TN + TM ? g - TN : 0] = FRAG(xs, wm * (BM / 2) + (g - TN) * 16 + frow, 4 + fgrp); \
+            _Pragma("unroll") for (int pc = 0; pc < NPC; pc++)                                 \
+                if (g == (pc * NG) / NPC) {                                                    \
+                    if (pc < XPW)                                                              \
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[pc < XPW ? pc : 0] + (dkt_) * BK), \
+                            (__attribute__((address_space(3))) void *)(Xs + ((buf_) ^ 1) * BM * BK + (wave * XPW + pc) * 512), 16, 0, 0); \
+                    else if constexpr (WT == W_F16)                                            \
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[pc - XPW >= 0 ? pc - XPW : 0] + (dkt_) * BK), \
+                            (__attribute__((address_space(3))) void *)(Ws + ((buf_) ^ 1) * BN * BK + (wave * WPW + pc - XPW) * 512), 16, 0, 0); \
+                }                                                                              \
+            _Pragma("unroll") for (int fr = NG; fr < TN + TM; fr++)   /* more fragments than groups: the rest in the last group */ \
+                if (g == NG - 1) {                                                             \
+                    if (fr < TN) wf[1][fr < TN ? fr : 0] = FRAG(ws, wn * (BN / 2) + fr * 16 + frow, 4 + fgrp); \
+                    else xf[1][fr - TN >= 0 ? fr - TN : 0] = FRAG(xs, wm * (BM / 2) + (fr - TN) * 16 + frow, 4 + fgrp); \
+                }                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
         }                                                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0); \
+        _Pragma("unroll") for (int g = 0; g < NG; g++) {                                       \
+            _Pragma("unroll") for (int i = 0; i < GS; i++) {                                   \
+                const int idx = g * GS + i;                                                    \
+                if (idx < NM) acc[idx / TM][idx % TM] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][idx / TM], xf[1][idx % TM], acc[idx / TM][idx % TM], 0, 0, 0); \
+            }                                                                                  \
+            if constexpr (WT != W_F16) {                                                       \
+                _Pragma("unroll") for (int wd = 0; wd < 4; wd++)                               \
+                    if (g == (wd * NG) / 4)                                                    \
+                        *(h8 *)(wrow_ + (((bkb * 4 + wd) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(BS[0], wd), wd); \
+            }                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
     }
 
     DMA_TILE(0, 0);
@@ -410,23 +410,14 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
     }
     } else
 #endif
-    if constexpr (WT == W_F16) {
+    if constexpr (ILV) {
     for (; kt + 1 < nk; kt += 2) {
-        READ0_MMA1(0);
-        DMA_TILE(1, kt + 1);
-        { const int t2 = kt + 2 < last ? kt + 2 : last; LOAD_B(B0, t2); }
-        STORE_B(B1, 1);
-        MMA0_READ1(0);
+        { const int t2 = kt + 2 < last ? kt + 2 : last; STEP_ILV(0, kt + 1, B0, t2, B1); }
         __syncthreads();
-        READ0_MMA1(1);
-        { const int t2 = kt + 2 < last ? kt + 2 : last; DMA_TILE(0, t2); }
-        { const int t3 = kt + 3 < last ? kt + 3 : last; LOAD_B(B1, t3); }
-        STORE_B(B0, 0);
-        MMA0_READ1(1);
+        { const int t2 = kt + 2 < last ? kt + 2 : last; const int t3 = kt + 3 < last ? kt + 3 : last; STEP_ILV(1, t2, B1, t3, B0); }
         __syncthreads();
     }
-    if (kt < nk) { READ0_MMA1(0); MMA0_READ1(0); }
-    MMA1();
+    if (kt < nk) COMPUTE(0);
     } else {
     for (; kt + 1 < nk; kt += 2) {
         DMA_TILE(1, kt + 1);
@@ -442,17 +433,13 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
     }
     if (kt < nk) COMPUTE(0);
     }
-#undef READ0
-#undef MMA1
-#undef READ0_MMA1
-#undef MMA0_READ1
+#undef STEP_ILV
+#undef FRAG
 #undef DMA_TILE
 #undef LOAD_B
 #undef STORE_B
 #undef COMPUTE
 #undef COMPUTE_SCHED
-#undef COMPUTE_PRIO_BEGIN
-#undef COMPUTE_PRIO_END
     asm volatile("" ::: "memory");
     if constexpr (SK) {
         if (ksplit > 1) {
