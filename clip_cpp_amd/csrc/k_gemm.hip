@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
 // LDS-DMA pieces of the next activation tile among the slice-0 MFMAs, the dequantisation + ds_write of the next weight
 // tile (one 8-weight word per slot) among the slice-1 MFMAs — so VALU / LDS / VMEM issue runs under the matrix pipe
 // instead of after it.
-    constexpr bool ILV = BM >= 128 && BN == 128;
+    constexpr bool ILV = BM >= 128 && BN >= 128;
     constexpr int NPC = XPW + (WT == W_F16 ? WPW : 0);   // LDS-DMA pieces per wave per K-step
     constexpr int NM = TN * TM, GS = 2, NG = (NM + GS - 1) / GS;
 #define FRAG(base_, row_, c_) (*(const h8 *)((base_) + lds_off((row_), (c_))))
@@ -381,9 +381,10 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
                 if (idx < NM) acc[idx / TM][idx % TM] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][idx / TM], xf[1][idx % TM], acc[idx / TM][idx % TM], 0, 0, 0); \
             }                                                                                  \
             if constexpr (WT != W_F16) {                                                       \
-                _Pragma("unroll") for (int wd = 0; wd < 4; wd++)                               \
-                    if (g == (wd * NG) / 4)                                                    \
-                        *(h8 *)(wrow_ + (((bkb * 4 + wd) ^ (bnl & 7)) << 3)) = dequant_wfrag<WT>(block_word<WT>(BS[0], wd), wd); \
+                _Pragma("unroll") for (int wd = 0; wd < 4 * NB; wd++)                          \
+                    if (g == (wd * NG) / (4 * NB))                                             \
+                        *(h8 *)(wrow_ + ((((bkb + (wd >> 2) * (NTHREADS / BN)) * 4 + (wd & 3)) ^ (bnl & 7)) << 3)) =       \
+                            dequant_wfrag<WT>(block_word<WT>(BS[wd >> 2], wd & 3), wd & 3);    \
             }                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                 \
         }                                                                                      \
@@ -509,8 +510,12 @@ void launch_tile(const GemmParams & p, int tile, hipStream_t stream) {
     case 128128: launch_dma<WT, 128, 128, EPI>(p, stream); break;
     case 160128: launch_dma<WT, 160, 128, EPI>(p, stream); break;
     case 192128: launch_dma<WT, 192, 128, EPI>(p, stream); break;
-    // BN = 256 tiles (128..256 x 256, one workgroup per CU, accumulators in AGPRs) compile and are correct but measured
-    // 10-40 % slower than the two-workgroups-per-CU tiles above (profiles/r01_gemm_bigtile_experiment.txt): not instantiated.
+#ifdef CLIPAMD_BIGTILES   // tuning builds: BN = 256 tiles, one workgroup per CU, accumulators in AGPRs
+    case 128256: launch_dma<WT, 128, 256, EPI>(p, stream); break;
+    case 160256: launch_dma<WT, 160, 256, EPI>(p, stream); break;
+    case 192256: launch_dma<WT, 192, 256, EPI>(p, stream); break;
+    case 256256: launch_dma<WT, 256, 256, EPI>(p, stream); break;
+#endif
     case 64128: launch_dma<WT, 64, 128, EPI>(p, stream); break;
     case 128064: launch_dma<WT, 128, 64, EPI>(p, stream); break;
     default: launch_dma<WT, 64, 64, EPI>(p, stream); break;
