@@ -42,6 +42,137 @@ struct AttnParams {
     int causal;
 };
 
+// Everything a wave needs to process query blocks of one (sequence, head): LDS tiles, global Q / output rows.
+template <int NT, int DKS, int DT>
+struct AttnTile {
+    const half_t * Ks;
+    const half_t * Vt;
+    const half_t * Qg;
+    half_t * Og;          // output rows of this sequence, already offset to the head's columns
+    int ld, h, len, causal, fq, fg;
+};
+
+// QB consecutive 16-query blocks starting at block qb0 (blocks beyond the sequence are computed on clamped rows and not stored).
+template <int NT, int DKS, int DT, int QB>
+__device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int qb0) {
+    constexpr int DKP = DKS * 32;
+    constexpr bool SWZ = NT > 18;
+    constexpr int KSTRIDE = SWZ ? DKP : DKP + 8;
+    constexpr int NPR = (NT + 1) / 2;
+    constexpr int VSTRIDE = NPR * 32 + 8;
+    constexpr int DH = DT * 16;
+    const int fq = t.fq, fg = t.fg, len = t.len;
+    // Q fragments (MFMA B operand): query row qb*16+fq, d = kk*32 + fg*8 .. +7
+    h8 qf[QB][DKS];
+    int qrow[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        qrow[j] = (qb0 + j) * 16 + fq;
+        const int qclamped = qrow[j] < len ? qrow[j] : len - 1;
+#pragma unroll
+        for (int kk = 0; kk < DKS; kk++) {
+            const int d0 = kk * 32 + fg * 8;
+            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+            if (d0 < DH) v = *(const u32x4 *)(t.Qg + (size_t)qclamped * t.ld + d0);
+            qf[j][kk] = __builtin_bit_cast(h8, v);
+        }
+    }
+    // ---- S^T tiles (unconditional MFMA chain); one K fragment read feeds QB MFMAs ----
+    f4 s[QB][NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+#pragma unroll
+        for (int j = 0; j < QB; j++) s[j][kt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DKS; kk++) {
+            const int kch = kk * 4 + fg;
+            const h8 kf = *(const h8 *)(t.Ks + (kt * 16 + fq) * KSTRIDE + (SWZ ? (kch ^ (fq & 7)) : kch) * 8);
+#pragma unroll
+            for (int j = 0; j < QB; j++) s[j][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[j][kk], s[j][kt], 0, 0, 0);
+        }
+        // keep at most 4 key tiles (8 fragment reads) in flight: fully hoisted, the reads of all NT tiles cost
+        // 4*2*NT VGPRs (NT = 18: 488 registers, one workgroup per CU)
+        if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- mask + softmax.  lane holds query fq, keys kt*16 + fg*4 + r ----
+    float inv[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        const int kmax = t.causal ? (qrow[j] < len - 1 ? qrow[j] : len - 1) : len - 1;   // last visible key
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = kt * 16 + fg * 4 + r;
+                s[j][kt][r] = key <= kmax ? s[j][kt][r] : -INFINITY;
+                mx = fmaxf(mx, s[j][kt][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = __expf(s[j][kt][r] - mx);   // key 0 is always visible -> mx is finite
+                s[j][kt][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[j] = 1.0f / sum;
+    }
+    // ---- O = P V : pairs of key tiles form one K=32 slice; one V^T fragment read feeds QB MFMAs ----
+    f4 o[QB][DT];
+#pragma unroll
+    for (int j = 0; j < QB; j++)
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) o[j][dt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < NPR; pr++) {
+        h8 pf[QB];
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            const f4 p0 = s[j][2 * pr];
+            f4 p1 = (f4){0.f, 0.f, 0.f, 0.f};
+            if (2 * pr + 1 < NT) p1 = s[j][(2 * pr + 1 < NT) ? 2 * pr + 1 : 0];
+            pf[j][0] = (_Float16)p0[0]; pf[j][1] = (_Float16)p0[1]; pf[j][2] = (_Float16)p0[2]; pf[j][3] = (_Float16)p0[3];
+            pf[j][4] = (_Float16)p1[0]; pf[j][5] = (_Float16)p1[1]; pf[j][6] = (_Float16)p1[2]; pf[j][7] = (_Float16)p1[3];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            const half_t * vrow = t.Vt + (dt * 16 + fq) * VSTRIDE + pr * 32 + fg * 4;
+            const h4 v0 = *(const h4 *)(vrow);
+            const h4 v1 = *(const h4 *)(vrow + 16);
+            h8 vf;
+            vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+            vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+#pragma unroll
+            for (int j = 0; j < QB; j++) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], vf, o[j][dt], 0, 0, 0);
+        }
+        if ((pr & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- normalise rows and store.  O layout: row (query) = fg*4 + r, col (d) = fq ----
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        float invr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) invr[r] = __shfl(inv[j], fg * 4 + r);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = (qb0 + j) * 16 + fg * 4 + r;
+            if (q < len) {
+                half_t * orow = t.Og + (size_t)q * t.h + fq;
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++) orow[dt * 16] = (_Float16)(o[j][dt][r] * invr[r]);
+            }
+        }
+    }
+}
+
 // NT  = number of 16-key tiles (>= ceil(max_len/16)); DKS = 32-wide k-steps over the head dim (dh <= 32*DKS);
 // DT = dh/16 output tiles.
 template <int NT, int DKS, int DT>
@@ -76,30 +207,54 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : 2)) attn_kernel(const Attn
     const half_t * Vg = Qg + 2 * p.h;
     constexpr int DCH = DH / 8;                      // 16-byte chunks per head row
 
-    // ---- stage K: Ks[key][0..DKP), zero for key >= len and for columns >= DH ----
+    // ---- stage K: Ks[key][0..DKP) (zero for key >= len and for columns >= DH) and V transposed: Vt[d][key], two keys per
+    // thread so every LDS store is a full dword.  ALL global loads of the workgroup are issued before the first LDS store
+    // (fully unrolled, unconditional clamped addresses + select): left as loops, each thread waited out one memory round
+    // trip per 16-byte chunk (9 + 2x5 serial trips at T = 257 — two thirds of the kernel's time).
     {
         constexpr int KCH = DKP / 8;
-        for (int it = tid; it < NT * 16 * KCH; it += 256) {
-            const int key = it / KCH, c = it % KCH;
-            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-            if (key < len && c < DCH) v = *(const u32x4 *)(Kg + (size_t)key * ld + c * 8);
-            *(u32x4 *)(Ks + key * KSTRIDE + (SWZ ? (c ^ (key & 7)) : c) * 8) = v;
-        }
-    }
-    // ---- stage V transposed: Vt[d][key]; two keys per thread so every LDS store is a full dword ----
-    {
+        constexpr int KIT = (NT * 16 * KCH + 255) / 256;
         constexpr int NPAIR = NPR * 16;              // key pairs (covers NPR*32 keys, zero padded)
-        for (int it = tid; it < NPAIR * DCH; it += 256) {
+        constexpr int VIT = (NPAIR * DCH + 255) / 256;
+        u32x4 kv[KIT], va[VIT], vb[VIT];
+#pragma unroll
+        for (int i = 0; i < KIT; i++) {
+            const int it = tid + i * 256;
+            const int key = it / KCH, c = it % KCH;
+            const int kc = key < len ? key : len - 1, cc = c < DCH ? c : DCH - 1;
+            kv[i] = *(const u32x4 *)(Kg + (size_t)kc * ld + cc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; i++) {
+            const int it = tid + i * 256;
+            const int kp = it % NPAIR, c = (it / NPAIR) < DCH ? (it / NPAIR) : DCH - 1;
+            const int k0 = 2 * kp;
+            va[i] = *(const u32x4 *)(Vg + (size_t)(k0 < len ? k0 : len - 1) * ld + c * 8);
+            vb[i] = *(const u32x4 *)(Vg + (size_t)(k0 + 1 < len ? k0 + 1 : len - 1) * ld + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; i++) {
+            const int it = tid + i * 256;
+            const int key = it / KCH, c = it % KCH;
+            if (it < NT * 16 * KCH) {
+                const u32x4 v = (key < len && c < DCH) ? kv[i] : (u32x4){0u, 0u, 0u, 0u};
+                *(u32x4 *)(Ks + key * KSTRIDE + (SWZ ? (c ^ (key & 7)) : c) * 8) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; i++) {
+            const int it = tid + i * 256;
             const int kp = it % NPAIR, c = it / NPAIR;
             const int k0 = 2 * kp;
-            u32x4 a = (u32x4){0u, 0u, 0u, 0u}, b = (u32x4){0u, 0u, 0u, 0u};
-            if (k0 < len) a = *(const u32x4 *)(Vg + (size_t)k0 * ld + c * 8);
-            if (k0 + 1 < len) b = *(const u32x4 *)(Vg + (size_t)(k0 + 1) * ld + c * 8);
+            if (it < NPAIR * DCH) {
+                const u32x4 a = k0 < len ? va[i] : (u32x4){0u, 0u, 0u, 0u};
+                const u32x4 b = k0 + 1 < len ? vb[i] : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint32_t av = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                const uint32_t bv = (b[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                *(uint32_t *)(Vt + (c * 8 + e) * VSTRIDE + k0) = av | (bv << 16);
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t av = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    const uint32_t bv = (b[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    *(uint32_t *)(Vt + (c * 8 + e) * VSTRIDE + k0) = av | (bv << 16);
+                }
             }
         }
     }
@@ -108,100 +263,16 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : 2)) attn_kernel(const Attn
     const int fq = lane & 15, fg = lane >> 4;
     const int nqb = (len + 15) >> 4;
 
-    for (int qb = wave; qb < nqb; qb += 4) {
-        // Q fragment (MFMA B operand): query row qb*16+fq, d = kk*32 + fg*8 .. +7
-        const int qrow = qb * 16 + fq;
-        const int qclamped = qrow < len ? qrow : len - 1;
-        h8 qf[DKS];
-#pragma unroll
-        for (int kk = 0; kk < DKS; kk++) {
-            const int d0 = kk * 32 + fg * 8;
-            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-            if (d0 < DH) v = *(const u32x4 *)(Qg + (size_t)qclamped * ld + d0);
-            qf[kk] = __builtin_bit_cast(h8, v);
-        }
-        // ---- S^T tiles (unconditional MFMA chain) ----
-        f4 s[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; kt++) {
-            s[kt] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < DKS; kk++) {
-                const int kch = kk * 4 + fg;
-                const h8 kf = *(const h8 *)(Ks + (kt * 16 + fq) * KSTRIDE + (SWZ ? (kch ^ (fq & 7)) : kch) * 8);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);
-            }
-            // keep at most 4 key tiles (8 fragment reads) in flight: fully hoisted, the reads of all NT tiles cost
-            // 4*2*NT VGPRs (NT = 18: 488 registers, one workgroup per CU)
-            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- mask + row max.  lane holds query fq, keys kt*16 + fg*4 + r ----
-        const int kmax = p.causal ? (qrow < len - 1 ? qrow : len - 1) : len - 1;   // last visible key
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; kt++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt * 16 + fg * 4 + r;
-                s[kt][r] = key <= kmax ? s[kt][r] : -INFINITY;
-                mx = fmaxf(mx, s[kt][r]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; kt++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float e = __expf(s[kt][r] - mx);   // key 0 is always visible -> mx is finite
-                s[kt][r] = e;
-                sum += e;
-            }
-        }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-
-        // ---- O = P V : pairs of key tiles form one K=32 slice ----
-        f4 o[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; dt++) o[dt] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pr = 0; pr < NPR; pr++) {
-            const f4 p0 = s[2 * pr];
-            f4 p1 = (f4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (true) {
-                if (2 * pr + 1 < NT) p1 = s[(2 * pr + 1 < NT) ? 2 * pr + 1 : 0];
-            }
-            h8 pf;
-            pf[0] = (_Float16)p0[0]; pf[1] = (_Float16)p0[1]; pf[2] = (_Float16)p0[2]; pf[3] = (_Float16)p0[3];
-            pf[4] = (_Float16)p1[0]; pf[5] = (_Float16)p1[1]; pf[6] = (_Float16)p1[2]; pf[7] = (_Float16)p1[3];
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++) {
-                const half_t * vrow = Vt + (dt * 16 + fq) * VSTRIDE + pr * 32 + fg * 4;
-                const h4 v0 = *(const h4 *)(vrow);
-                const h4 v1 = *(const h4 *)(vrow + 16);
-                h8 vf;
-                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[dt], 0, 0, 0);
-            }
-            if ((pr & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- normalise rows and store.  O layout: row (query) = fg*4 + r, col (d) = fq ----
-        float invr[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) invr[r] = __shfl(inv, fg * 4 + r);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int q = qb * 16 + fg * 4 + r;
-            if (q < len) {
-                half_t * orow = p.out + (size_t)(row0 + q) * p.h + head * DH + fq;
-#pragma unroll
-                for (int dt = 0; dt < DT; dt++) orow[dt * 16] = (_Float16)(o[dt][r] * invr[r]);
-            }
-        }
+    // Query blocks are processed in PAIRS where the register budget allows (QB = 2: every K / V^T fragment read from LDS
+    // feeds two MFMAs, halving the LDS traffic that bounds this kernel at T = 257), the odd last block alone.
+    constexpr int QB = (NT >= 7 && NT <= 18) ? 2 : 1;
+    const AttnTile<NT, DKS, DT> t{Ks, Vt, Qg, p.out + (size_t)row0 * p.h + head * DH, ld, p.h, len, p.causal, fq, fg};
+    if constexpr (QB == 2) {
+        const int npair = nqb >> 1;
+        for (int u = wave; u < npair; u += 4) attn_blocks<NT, DKS, DT, 2>(t, 2 * u);
+        if ((nqb & 1) && wave == (npair & 3)) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
+    } else {
+        for (int qb = wave; qb < nqb; qb += 4) attn_blocks<NT, DKS, DT, 1>(t, qb);
     }
 }
 
