@@ -99,24 +99,31 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
 #pragma unroll
     for (int j = 0; j < QB; j++) {
         const int kmax = t.causal ? (qrow[j] < len - 1 ? qrow[j] : len - 1) : len - 1;   // last visible key
+        const int kfull = t.causal ? 0 : (len >> 4);     // key tiles below kfull are entirely visible (uniform): no masking work
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NT; kt++) {
+            if (kt >= kfull) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt * 16 + fg * 4 + r;
-                s[j][kt][r] = key <= kmax ? s[j][kt][r] : -INFINITY;
-                mx = fmaxf(mx, s[j][kt][r]);
+                for (int r = 0; r < 4; r++) {
+                    const int key = kt * 16 + fg * 4 + r;
+                    s[j][kt][r] = key <= kmax ? s[j][kt][r] : -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[j][kt][r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // exp(s - mx) = exp2(s*log2(e) - mx*log2(e)): one fma + the hardware exp2 per score
+        const float L2E = 1.44269504088896340736f;
+        const float nmx = -mx * L2E;                     // key 0 is always visible -> mx is finite
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; kt++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float e = __expf(s[j][kt][r] - mx);   // key 0 is always visible -> mx is finite
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][r], L2E, nmx));
                 s[j][kt][r] = e;
                 sum += e;
             }
