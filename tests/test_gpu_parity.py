@@ -177,6 +177,29 @@ def test_large_model_shapes_quantised(gpu, fixture_cache, config, ftype):
     assert one_minus_cos(clip.encode_images(imgs[:1]), got[:1])[0] <= 1e-6
 
 
+def test_batches_beyond_one_workspace_chunk_and_stream_restore(gpu, fixture_cache):
+    """More images than one forward chunk (1024) and than one host-API staging chunk (256): rows must equal the small-batch
+    results bit for bit (tiny model: no split-K at any size); clip_amd_set_stream(NULL) restores the context's own stream."""
+    torch = pytest.importorskip("torch")
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=False, vision=True)
+    clip = gpu.Clip(p, device=0)
+    imgs = fixtures.synthetic_images(1030, 32, seed=77)
+    full = clip.encode_images(imgs)                                   # host API: 5 staging chunks
+    assert full.shape == (1030, 32) and np.all(np.isfinite(full))
+    for i in (0, 255, 256, 1023, 1024, 1029):
+        assert np.array_equal(clip.encode_images(imgs[i:i + 1])[0], full[i]), i
+    d_in = torch.from_numpy(imgs).cuda()
+    d_out = torch.empty((1030, 32), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        clip.set_stream(st.cuda_stream)
+        clip.encode_images_device(d_in.data_ptr(), 1030, d_out.data_ptr())   # device API: two forward chunks (1024 + 6)
+        st.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), full)
+    clip.set_stream(0)                                                 # NULL -> own stream again
+    assert np.array_equal(clip.encode_images(imgs[:3]), full[:3])
+
+
 def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
     torch = pytest.importorskip("torch")
     p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
