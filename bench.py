@@ -57,7 +57,7 @@ def main():
     import torch.distributed as dist
 
     import clip_cpp_amd
-    from oracle import fixtures   # fixture WRITER only (synthetic GGUF); the oracle model is used for cpu_baseline below
+    from clip_cpp_amd import synth   # synthetic GGUF through the product's own writer + clip_model_quantize (no oracle/ in the measured path)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +75,7 @@ def main():
 
     n_texts = 0 if args.vision_only else (args.batch if args.texts < 0 else args.texts)
     cache = os.environ.get("CLIP_AMD_FIXTURE_CACHE", "/tmp/clip_amd_fixtures")
-    path = fixtures.cached_model(cache, args.model, args.ftype, text=not args.vision_only, vision=True, seed=1234)
+    path = synth.cached_model(cache, args.model, args.ftype, text=not args.vision_only, vision=True, seed=1234)
     clip = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
     vc, tc = clip.vision_config, clip.text_config
     if args.vision_only:
@@ -90,7 +90,7 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(1000 + rank)
     imgs = torch.randn((args.batch, S, S, 3), dtype=torch.float32, device="cuda", generator=g)
-    texts = fixtures.synthetic_token_ids(n_texts, seed=11 + rank, min_len=1, max_len=min(75, tc["num_positions"] - 2))
+    texts = synth.token_ids(n_texts, seed=11 + rank, min_len=1, max_len=min(75, tc["num_positions"] - 2))
     flat = np.concatenate(texts).astype(np.int32) if n_texts else np.zeros(1, np.int32)
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
     d_ids = torch.from_numpy(flat).cuda()

@@ -227,3 +227,27 @@ def test_reference_programs_build_unchanged_against_this_library(clip_lib, tmp_p
     cmd += ["-L", libdir, "-lclip", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "prog")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_product_side_synthetic_models_load_everywhere(tmp_path, clip_lib):
+    """clip_cpp_amd.synth (what bench.py uses: product GGUF writer + clip_model_quantize, no oracle/ involved) writes files
+    with the reference's tensor inventory that both libclip.so and the oracle accept."""
+    from clip_cpp_amd import synth
+    env_had = os.environ.get("CLIP_AMD_ALLOW_NO_DEVICE")
+    os.environ["CLIP_AMD_ALLOW_NO_DEVICE"] = "1"
+    try:
+        for ftype, text, vision, n in [("q4_0", True, True, 77), ("f16", False, True, 40), ("q8_0", True, False, 37)]:
+            p = synth.cached_model(str(tmp_path), "tiny", ftype, text=text, vision=vision)
+            kv, tensors = clip_lib.gguf_inspect(p)
+            assert len(tensors) == n and kv["general.file_type"] == synth.FTYPES[ftype]
+            o = ref.OracleModel(p)
+            assert o.info["has_text"] == int(text) and o.info["has_vision"] == int(vision) and o.info["ftype"] == synth.FTYPES[ftype]
+            c = clip_lib.Clip(p)
+            if text:
+                assert c.tokenize("a b")[0] == 49406 and len(kv["tokenizer.ggml.tokens"]) == 49408
+        # the tensor inventory of the full-size architectures matches the counts the reference switches on (clip.cpp:267-289)
+        assert len(synth.tensor_list(synth.ARCH["b32"])) == 397 and len(synth.tensor_list(synth.ARCH["l14"])) == 589
+        assert len(synth.tensor_list(synth.ARCH["h14"])) == 909 and len(synth.tensor_list(synth.ARCH["b32"], text=False)) == 200
+    finally:
+        if env_had is None:
+            os.environ.pop("CLIP_AMD_ALLOW_NO_DEVICE", None)
