@@ -102,6 +102,31 @@ __global__ void __launch_bounds__(256) im2col_kernel(const float * __restrict__ 
     *(uint32_t *)(col + (size_t)m * Kpad + k0) = __builtin_bit_cast(uint32_t, o);
 }
 
+
+// Coalesced form for even P: one thread per (patch, ky, pixel pair).  It reads 6 consecutive floats of the interleaved
+// image row (RGB RGB) and writes one half2 into each of the three channel planes of the patch row, so a wave reads
+// 1.5 KB contiguous and writes three 256-byte runs (the scalar kernel above strides the reads by 12 bytes).
+__global__ void __launch_bounds__(256) im2col_rows_kernel(const float * __restrict__ imgs, half_t * __restrict__ col, int S, int P,
+                                                          int Kpad, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int hp = P >> 1;
+    const int xp = (int)(i % hp);
+    const long r = i / hp;
+    const int ky = (int)(r % P);
+    const long m = r / P;
+    const int G = S / P, Np = G * G;
+    const int b = (int)(m / Np), pp = (int)(m % Np);
+    const int oy = pp / G, ox = pp % G;
+    const float * src = imgs + (size_t)b * S * S * 3 + 3 * ((size_t)(oy * P + ky) * S + (ox * P + 2 * xp));
+    const float2 a = *(const float2 *)(src), c = *(const float2 *)(src + 2), e = *(const float2 *)(src + 4);   // r0 g0 | b0 r1 | g1 b1
+    half_t * dst = col + (size_t)m * Kpad + ky * P + 2 * xp;
+    const h2 rr = (h2){(_Float16)a.x, (_Float16)c.y}, gg = (h2){(_Float16)a.y, (_Float16)e.x}, bb = (h2){(_Float16)c.x, (_Float16)e.y};
+    *(uint32_t *)(dst) = __builtin_bit_cast(uint32_t, rr);
+    *(uint32_t *)(dst + P * P) = __builtin_bit_cast(uint32_t, gg);
+    *(uint32_t *)(dst + 2 * P * P) = __builtin_bit_cast(uint32_t, bb);
+}
+
 __global__ void __launch_bounds__(256) cls_rows_kernel(float * __restrict__ x, const float * __restrict__ cls,
                                                        const float * __restrict__ pos, int B, int T, int h) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -224,6 +249,11 @@ void launch_im2col(const float * imgs, half_t * col, int B, int S, int P, int Kp
     const int G = S / P;
     const long total2 = (long)B * G * G * (Kpad / 2);
     if (total2 <= 0) return;
+    if (P % 2 == 0 && Kpad == 3 * P * P && S % 2 == 0) {   // no K padding to zero-fill, 8-byte aligned pixel pairs
+        const long total = (long)B * G * G * P * (P / 2);
+        hipLaunchKernelGGL(im2col_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, imgs, col, S, P, Kpad, total);
+        return;
+    }
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, imgs, col, B, S, P, Kpad,
                        total2);
 }
