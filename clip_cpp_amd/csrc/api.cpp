@@ -254,11 +254,11 @@ bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, c
     }
     (void)hipSetDevice(ctx->device);
     const int proj = ctx->text_hparams.projection_dim;
-    DBuf d_ids(ids.size() * 4), d_out(n_texts * (size_t)proj * 4);
-    if (!d_ids.p || !d_out.p) { fprintf(stderr, "clip_text_encode: out of device memory\n"); return false; }
-    bool ok = hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-    ok = ok && text_forward_device(ctx, (const int32_t *)d_ids.p, off.data(), (int)n_texts, (float *)d_out.p, normalize);
-    ok = ok && hipMemcpyAsync(vec, d_out.p, n_texts * (size_t)proj * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    // persistent device staging (ids in io_in, embeddings in io_out): no hipMalloc / hipFree on the per-call path
+    if (!ensure_io(ctx, ids.size() * 4, n_texts * (size_t)proj * 4)) { fprintf(stderr, "clip_text_encode: out of device memory\n"); return false; }
+    bool ok = hipMemcpyAsync(ctx->io_in, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && text_forward_device(ctx, (const int32_t *)ctx->io_in, off.data(), (int)n_texts, (float *)ctx->io_out, normalize);
+    ok = ok && hipMemcpyAsync(vec, ctx->io_out, n_texts * (size_t)proj * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (ctx->profiling) prof_collect(ctx);
     return ok;

@@ -152,6 +152,11 @@ void drop_graphs(clip_ctx * ctx) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     ctx->vgraphs.clear();
+    for (auto & g : ctx->tgraphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->tgraphs.clear();
 }
 
 bool ensure_workspace(clip_ctx * ctx, size_t bytes) {
@@ -376,14 +381,48 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         (void)hipMemcpyAsync(last, hs.data() + n_texts + 1, (size_t)n_texts * 4, hipMemcpyHostToDevice, s);
         (void)hipStreamSynchronize(s);
     }
-    launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
-    if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
-    // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
-    launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
-    GemmParams pj;
-    pj.A = pooled; pj.lda = h; pj.M = n_texts; pj.W = Tw.proj; pj.out = emb; pj.ldc = proj;
-    gemm(ctx, "gemm_proj", pj, EPI_F32);     // (:1160)
-    launch_l2norm(emb, d_out, n_texts, proj, normalize, s);  // (:1163-1166)
+    auto launch_all = [&]() -> bool {
+        launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
+        if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
+        // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
+        launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+        GemmParams pj;
+        pj.A = pooled; pj.lda = h; pj.M = n_texts; pj.W = Tw.proj; pj.out = emb; pj.ldc = proj;
+        gemm(ctx, "gemm_proj", pj, EPI_F32);     // (:1160)
+        launch_l2norm(emb, d_out, n_texts, proj, normalize, s);  // (:1163-1166)
+        return true;
+    };
+    // Small token counts are launch-bound (~90 dependent launches): capture the chain on the second sighting of a signature and
+    // replay it afterwards.  The kernels read the sequence offsets from device memory (uploaded above), so a graph only depends on
+    // (texts, token rows, attention key-tile bucket, pointers) — not on the individual lengths.
+    const int nt_bucket = (max_len + 15) / 16;
+    if (ctx->graphs_enabled && !ctx->profiling && rows <= 1024) {
+        clip_ctx::TextGraphEntry * e = nullptr;
+        const void * ids_key = d_ids + h_offsets[0];
+        for (auto & g : ctx->tgraphs)
+            if (g.n_texts == n_texts && g.rows == rows && g.nt == nt_bucket && g.ids == ids_key && g.out == d_out && g.norm == normalize) { e = &g; break; }
+        if (e && e->exec) return hipGraphLaunch(e->exec, s) == hipSuccess;
+        if (!e) {
+            if (ctx->tgraphs.size() >= 96) drop_graphs(ctx);
+            ctx->tgraphs.push_back({n_texts, rows, nt_bucket, ids_key, d_out, normalize, 1, nullptr, nullptr});
+        } else if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const bool ok = launch_all();
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            hipGraphExec_t exec = nullptr;
+            if (ok && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                e->graph = graph;
+                e->exec = exec;
+                return hipGraphLaunch(exec, s) == hipSuccess;
+            }
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            ctx->graphs_enabled = false;      // capture not possible here: stay eager from now on
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (!launch_all()) return false;
     return launch_ok("clip_text_encode");
 }
 

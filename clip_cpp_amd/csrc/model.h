@@ -100,6 +100,10 @@ struct clip_ctx {
     // second time the same (batch, input pointer, output pointer, normalize) signature is seen and replayed afterwards.
     struct GraphEntry { int B; const void * in; void * out; bool norm; int seen; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<GraphEntry> vgraphs;
+    // ... and for the text forward at small token counts (single texts, short label lists): keyed on (texts, token rows,
+    // attention key-tile bucket, pointers); the per-call sequence offsets live in device memory and are uploaded before the replay
+    struct TextGraphEntry { int n_texts, rows, nt; const void * ids; void * out; bool norm; int seen; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<TextGraphEntry> tgraphs;
     bool graphs_enabled = true;      // CLIP_AMD_GRAPHS=0 disables
 
     int verbosity = 0;

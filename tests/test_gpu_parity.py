@@ -318,6 +318,29 @@ def test_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
     assert np.array_equal(one[0], ea[0])
 
 
+def test_text_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
+    """Single texts / short lists replay a captured hipGraph from the third call with the same (texts, tokens) signature on:
+    eager == capture == replay, a replay sees NEW ids and NEW per-text lengths (same total), and a fresh context agrees."""
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    clip, fresh = gpu.Clip(p, device=0), gpu.Clip(p, device=0)
+    a = [49406, 11, 12, 13, 14, 49407]
+    b = [49406, 21, 22, 23, 24, 49407]
+    ea = np.asarray(clip.encode_text(a), dtype=np.float32)
+    for _ in range(4):
+        assert np.array_equal(np.asarray(clip.encode_text(a), dtype=np.float32), ea)
+    eb = np.asarray(clip.encode_text(b), dtype=np.float32)                       # replay with new ids
+    assert not np.array_equal(ea, eb)
+    assert np.array_equal(eb, np.asarray(fresh.encode_text(b), dtype=np.float32))  # fresh context = eager
+    # ragged lists with the same totals but different splits share one graph (offsets are device data)
+    l1 = [np.array([49406, 5, 6, 49407], np.int32), np.array([49406, 7, 8, 9, 10, 11, 49407], np.int32)]
+    l2 = [np.array([49406, 5, 6, 9, 10, 11, 49407], np.int32), np.array([49406, 7, 8, 49407], np.int32)]
+    for _ in range(3):
+        r1 = clip.encode_texts(l1)
+    r2 = clip.encode_texts(l2)                                                    # replay: other lengths, same rows / bucket
+    np.testing.assert_array_equal(r1, fresh.encode_texts(l1))
+    np.testing.assert_array_equal(r2, fresh.encode_texts(l2))
+
+
 def test_reference_example_main_runs_unchanged_on_the_gpu_library(gpu, fixture_cache, tmp_path):
     """BASELINE config 1 ("plumbing"): the reference's examples/main.cpp, compiled unchanged against include/ and linked to
     libclip.so (oracle/_ref/ref_main, built in the dev container by `make -C oracle ref`), loads a ViT-B/32 f16 two-tower GGUF,
