@@ -1,0 +1,34 @@
+"""bench.py prints ONE JSON line with the contract's fields (incl. `roofline` and `cpu_baseline`); smoke() runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat", "0.2", "--model", "tiny",
+                        "--ftype", "q4_0", "--batch", "16", "--cpu-sample", "4"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                          # exactly one line on stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["value"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["gpu_vs_cpu_1_minus_cos_max"] <= 1e-3
+
+
+def test_graft_entry_smoke_runs():
+    r = subprocess.run([sys.executable, "__graft_entry__.py", "--smoke"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
