@@ -203,6 +203,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
     }
 }
 
+// ---- f16-output epilogue staged through LDS (qkv / FFN-up): written straight from the accumulator layout, a wave store
+// covers 16 rows x 32 B — quarter cache lines, measured ~3 TB/s and 27-31 % of those GEMMs' time (profiles/).  Instead each
+// wave parks its (BM/2) x (BN/2) fp16 sub-tile in its own LDS region (rows padded to 136 B: conflict-free 8-byte writes)
+// and re-reads it row-contiguous, so every global store instruction writes 8 full 128-byte lines.
+// Requires BN/2 == 64, the whole n range of the wave inside N, and a 16-byte aligned output row (ldc % 8 == 0).
+template <int EPI, int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
+                                                         half_t * stage, int lane) {
+    constexpr int RS = 68;                                     // halfs per staged row (64 + 4 pad = 136 B)
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        const int n = nbase + a * 16 + fgrp * 4;
+        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *(const f4 *)(p.bias + n);
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            f4 v = acc[a][b] + bias;
+            if constexpr (EPI == EPI_F16) {
+                if (n < p.qcols) v = v * p.qscale;
+            } else if constexpr (EPI == EPI_GELU_F16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
+            } else if constexpr (EPI == EPI_QGELU_F16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
+            }
+            const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
+            const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
+            *(uint2 *)(stage + (b * 16 + frow) * RS + a * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
+        }
+    }
+    // the region is private to this wave: no barrier, the LDS writes are ordered before the reads by lgkmcnt
+    const int rrow = lane >> 3, rchunk = lane & 7;
+#pragma unroll
+    for (int i = 0; i < TM * 2; i++) {
+        const int ml = i * 8 + rrow;
+        const int m = mbase + ml;
+        const u32x4 v = *(const u32x4 *)(stage + ml * RS + rchunk * 8);
+        if (m < p.M) *(u32x4 *)((half_t *)p.out + (size_t)m * p.ldc + nbase + rchunk * 8) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA variant: fp16 tiles (X always, W when the weights are f16) go HBM/L2 -> LDS with
 // global_load_lds_dwordx4 (no VGPR round trip, no ds_write): one wave-instruction moves a 1 KB piece = 8 tile rows;
@@ -487,6 +529,14 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
                         acc[a][b] += (f4){lo.x, lo.y, hi.x, hi.y};
                     }
             }
+        }
+    }
+    if constexpr ((EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) && BN == 128 && BM >= 128) {
+        const int nb = n0 + wn * (BN / 2);
+        if (nb + BN / 2 <= p.W.N && (p.ldc & 7) == 0) {                 // uniform per wave
+            if (nk & 1) __syncthreads();                                 // odd K-step count: the tail COMPUTE(0) had no barrier behind it
+            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, m0 + wm * (BM / 2), frow, fgrp, (half_t *)smem_raw + wave * (BM / 2) * 68, lane);
+            return;
         }
     }
     gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
