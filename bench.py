@@ -1,21 +1,30 @@
 #!/usr/bin/env python
 """bench.py — image+text embeddings/sec of the MI355X-native CLIP encoder (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 One "step" = one pass of the hot path over one batch of synthetic input that is ALREADY resident in HBM:
 `clip_amd_image_batch_encode_device` on B preprocessed images + `clip_amd_text_batch_encode_device` on B
 ragged token sequences, both through the C ABI of libclip.so, then (N > 1) ONE RCCL all-gather of the
 final embeddings.  Per-GPU work is fixed as N grows ("weak" scaling).  Weights are seeded synthetic
-(no real checkpoints exist offline) in the ViT-B/32 architecture, q4_0 file type.
+(no real checkpoints exist offline) in the named architecture and file type.
+
+Default workload = the configuration BASELINE.json's metric is quoted on: ViT-B/32 q4_0, batch 256 (+ 256 texts).
+`--config` selects the other rows of the north_star target matrix (ViT-B/32 q4_0 and ViT-L/14 f16 at batch 1 / 32 / 256)
+and the BASELINE configs 2-5 in their single-GPU forms; see CONFIGS.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus
-  "roofline"     — dominant kernel (the dequant-GEMM instantiation with the largest total time), timed
-                   live with HIP events on the launch stream in a second pass of the same K steps
-  "cpu_baseline" — the CPU oracle (restatement of the ggml path; ggml itself is absent) on a bounded sample.
+  "roofline"            — dominant kernel (the GEMM instantiation with the largest total time), timed live with HIP events
+                          on the launch stream in a second pass of the same K steps
+  "whole_step_roofline" — SURVEY 8(d) algorithmic FLOPs / bytes of the whole step against ms_per_step
+  "cpu_baseline"        — the CPU oracle (restatement of the ggml path; ggml itself is absent) on a bounded sample, all host
+                          cores and the reference harness's chunk-of-4 / 4-thread form (tests/benchmark.cpp:50-51), with the
+                          GPU-vs-oracle cosine deltas of BOTH towers on that sample
+  "host_api_images_per_s" — the drop-in host-pointer API (clip_image_batch_encode from pageable caller buffers), PCIe included.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,20 +39,39 @@ if ROOT not in sys.path:
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
+# name -> model, file type, images per GPU per step, texts per GPU per step (None = same as images), default steps
+CONFIGS = {
+    "b32_q4_0_b256": dict(model="b32", ftype="q4_0", batch=256, texts=None, steps=20),   # BASELINE metric (default)
+    "b32_q4_0_b32": dict(model="b32", ftype="q4_0", batch=32, texts=None, steps=50),
+    "b32_q4_0_b1": dict(model="b32", ftype="q4_0", batch=1, texts=None, steps=100),
+    "l14_f16_b256": dict(model="l14", ftype="f16", batch=256, texts=None, steps=5),
+    "l14_f16_b32": dict(model="l14", ftype="f16", batch=32, texts=None, steps=20),
+    "l14_f16_b1": dict(model="l14", ftype="f16", batch=1, texts=None, steps=50),
+    # BASELINE.json configs[1..4] (image encode only), single-GPU forms
+    "cfg2_b32_q4_0_b32_img": dict(model="b32", ftype="q4_0", batch=32, texts=0, steps=50),
+    "cfg3_l14_f16_b256_img": dict(model="l14", ftype="f16", batch=256, texts=0, steps=5),
+    "cfg4_l14_q5_1_b128_img": dict(model="l14", ftype="q5_1", batch=128, texts=0, steps=5),   # 1024 / 8 GPUs
+    "cfg5_h14_q8_0_b64_img": dict(model="h14", ftype="q8_0", batch=64, texts=0, steps=5),
+    "b32_q4_0_b256_img": dict(model="b32", ftype="q4_0", batch=256, texts=0, steps=20),
+}
+BITS_PER_WEIGHT = {"f32": 32.0, "f16": 16.0, "q4_0": 4.5, "q4_1": 5.0, "q5_0": 5.5, "q5_1": 6.0, "q8_0": 8.5}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=-1)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="b32")
-    ap.add_argument("--ftype", default="q4_0")
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--config", default="b32_q4_0_b256", choices=sorted(CONFIGS), help="workload preset (default = the BASELINE metric configuration)")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--ftype", default=None)
+    ap.add_argument("--batch", type=int, default=-1, help="images per GPU per step")
     ap.add_argument("--texts", type=int, default=-1, help="texts per GPU per step (default = batch)")
     ap.add_argument("--vision-only", action="store_true", help="vision tower only (implies --texts 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32, help="images (and texts) of the workload timed on the CPU oracle: ~20-30 core-seconds")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="images (and texts) of the workload timed on the CPU oracle (default: ~20-30 core-seconds)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--preheat", type=float, default=1.0,
                     help="seconds of untimed stepping BEFORE the W warm-up steps (a cold MI355X needs ~0.5 s of load to reach its "
                          "sustained clocks: measured 7.6 ms/step for the first process on a fresh box vs 5.9 ms once warm)")
@@ -54,6 +82,39 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_source_sha16():
+    """Identity of the kernel sources a PMC traffic file was measured at (profiles/pmc_traffic.json carries it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "clip_cpp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".hip") or f == "kernels.h":
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_work(vc, tc, ftype, n_img, text_lens):
+    """SURVEY 8(d): FLOPs = 2 x MACs of the weight GEMMs, attention and patch embedding (elementwise excluded);
+    bytes = weight bytes once + inputs + outputs (intermediates are not algorithmic)."""
+    bpw = BITS_PER_WEIGHT[ftype] / 8.0
+    fl = by = 0.0
+    if n_img:
+        S, P, h, ff, L, proj = vc["image_size"], vc["patch_size"], vc["hidden_size"], vc["n_intermediate"], vc["n_layer"], vc["projection_dim"]
+        Np = (S // P) ** 2
+        T = Np + 1
+        per_img = 2.0 * Np * h * 3 * P * P + L * (2.0 * T * (4 * h * h + 2 * h * ff) + 4.0 * T * T * h) + 2.0 * h * proj
+        fl += n_img * per_img
+        wbytes = L * (4 * h * h + 2 * h * ff) * bpw + h * proj * bpw + T * h * bpw + h * 3 * P * P * 2 + (L * (9 * h + ff) + 5 * h) * 4
+        by += wbytes + n_img * (S * S * 3 * 4 + proj * 4)
+    if len(text_lens):
+        h, ff, L, proj = tc["hidden_size"], tc["n_intermediate"], tc["n_layer"], tc["projection_dim"]
+        for n in text_lens:
+            fl += 2.0 * L * n * (4 * h * h + 2 * h * ff) + 4.0 * L * n * n * h + 2.0 * h * proj
+        rows = float(sum(text_lens))
+        wbytes = L * (4 * h * h + 2 * h * ff) * bpw + h * proj * bpw + tc["num_positions"] * h * bpw + (L * (9 * h + ff) + 2 * h) * 4
+        by += wbytes + rows * (h * bpw + 4) + len(text_lens) * proj * 4     # token-embedding rows actually gathered + ids
+    return fl, by
+
+
 def main():
     args = parse()
     import torch
@@ -61,6 +122,18 @@ def main():
 
     import clip_cpp_amd
     from clip_cpp_amd import synth   # synthetic GGUF through the product's own writer + clip_model_quantize (no oracle/ in the measured path)
+
+    cfg = dict(CONFIGS[args.config])
+    if args.model: cfg["model"] = args.model
+    if args.ftype: cfg["ftype"] = args.ftype
+    if args.batch > 0: cfg["batch"] = args.batch
+    if args.texts >= 0: cfg["texts"] = args.texts
+    if args.vision_only: cfg["texts"] = 0
+    steps = args.steps if args.steps > 0 else cfg["steps"]
+    batch = cfg["batch"]
+    n_texts = batch if cfg["texts"] is None else cfg["texts"]
+    vision_only = n_texts == 0
+    custom = bool(args.model or args.ftype or args.batch > 0 or args.texts >= 0 or args.vision_only)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,20 +149,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    n_texts = 0 if args.vision_only else (args.batch if args.texts < 0 else args.texts)
     cache = os.environ.get("CLIP_AMD_FIXTURE_CACHE", "/tmp/clip_amd_fixtures")
-    path = synth.cached_model(cache, args.model, args.ftype, text=not args.vision_only, vision=True, seed=1234)
+    path = synth.cached_model(cache, cfg["model"], cfg["ftype"], text=not vision_only, vision=True, seed=1234)
     clip = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
     vc, tc = clip.vision_config, clip.text_config
-    if args.vision_only:
+    if vision_only:
         tc = dict(tc, num_positions=77)
     S, proj = vc["image_size"], vc["projection_dim"]
     # a dedicated (non-null) torch stream carries the HIP kernels AND the RCCL all-gather, so they are ordered
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     clip.set_stream(stream.cuda_stream)
-    # the two towers of a step are independent: the text tower gets its own context (own workspace; 2nd copy of the 85 MB of
-    # weights) and its own stream, joined back into the main stream before the step ends
+    # the two towers of a step are independent: the text tower gets its own context (own workspace; 2nd copy of the weights)
+    # and its own stream, joined back into the main stream before the step ends
     overlap = n_texts > 0 and not args.no_overlap
     if overlap:
         clip_t = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
@@ -101,18 +173,20 @@ def main():
     # synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device="cuda")
     g.manual_seed(1000 + rank)
-    imgs = torch.randn((args.batch, S, S, 3), dtype=torch.float32, device="cuda", generator=g)
+    imgs = torch.randn((batch, S, S, 3), dtype=torch.float32, device="cuda", generator=g)
     texts = synth.token_ids(n_texts, seed=11 + rank, min_len=1, max_len=min(75, tc["num_positions"] - 2))
     flat = np.concatenate(texts).astype(np.int32) if n_texts else np.zeros(1, np.int32)
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
     d_ids = torch.from_numpy(flat).cuda()
-    emb = torch.empty((args.batch + n_texts, proj), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((N * (args.batch + n_texts), proj), dtype=torch.float32, device="cuda") if N > 1 else None
-    img_out = emb[: args.batch]
-    txt_out = emb[args.batch:]
+    emb = torch.empty((batch + n_texts, proj), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((N * (batch + n_texts), proj), dtype=torch.float32, device="cuda") if N > 1 else None
+    img_out = emb[:batch]
+    txt_out = emb[batch:]
 
     def local_step():
-        clip.encode_images_device(imgs.data_ptr(), args.batch, img_out.data_ptr(), True)
+        if overlap:
+            tstream.wait_stream(stream)          # fork: the text tower of this step starts with the vision tower
+        clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True)
         if n_texts:
             clip_t.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True)
             if overlap:
@@ -137,7 +211,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     sync()
     dt = time.perf_counter() - t0
@@ -145,28 +219,39 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    per_step_units = N * (args.batch + n_texts)
-    value = per_step_units * args.steps / dt
+    per_step_units = N * (batch + n_texts)
+    value = per_step_units * steps / dt
     assert bool(torch.isfinite(emb).all()), "non-finite embeddings"
 
     # separate image-only / text-only rates (rank-local, informative)
     def rate(fn, units):
         fn(); torch.cuda.synchronize()
+        n = max(3, steps // 2)
         t = time.perf_counter()
-        for _ in range(max(3, args.steps // 2)):
+        for _ in range(n):
             fn()
         torch.cuda.synchronize()
-        return units * max(3, args.steps // 2) / (time.perf_counter() - t)
+        return units * n / (time.perf_counter() - t)
 
-    img_rate = rate(lambda: clip.encode_images_device(imgs.data_ptr(), args.batch, img_out.data_ptr(), True), args.batch)
+    img_rate = rate(lambda: clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True), batch)
     txt_rate = rate(lambda: clip.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True), n_texts) if n_texts else 0.0
+
+    # whole-step roofline: algorithmic work of one GPU's step against the measured step time
+    fl_step, by_step = algorithmic_work(vc, tc, cfg["ftype"], batch, [len(t) for t in texts])
+    ms_step = dt / steps * 1e3
+    t_mfma_ws, t_hbm_ws = fl_step / (MFMA_F16_PEAK_TFLOPS * 1e12), by_step / (HBM_PEAK_GBS * 1e9)
+    ws_bound = "mfma" if t_mfma_ws >= t_hbm_ws else "hbm"
+    whole = {"bound": ws_bound, "algorithmic_flops_per_step": fl_step, "algorithmic_bytes_per_step": by_step,
+             "t_mfma_us": round(t_mfma_ws * 1e6, 2), "t_hbm_us": round(t_hbm_ws * 1e6, 2),
+             "achieved_tflops": round(fl_step / (ms_step * 1e-3) / 1e12, 2), "achieved_gbs": round(by_step / (ms_step * 1e-3) / 1e9, 1),
+             "frac": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4)}
 
     roofline = None
     kernels = None
     if not args.no_roofline and rank == 0:
         clip.profile(True)
-        for _ in range(args.steps):
-            clip.encode_images_device(imgs.data_ptr(), args.batch, img_out.data_ptr(), True)
+        for _ in range(steps):
+            clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True)
             if n_texts:
                 clip.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True)
         torch.cuda.synchronize()
@@ -188,14 +273,22 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in rep.values())
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc (scripts/gpu_pmc.sh)
+            traffic_note = "no profiles/pmc_traffic.json"
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc (scripts/gpu_round.sh)
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+                    tj = json.load(open(tpath))
+                    if tj.get("_kernel_src_sha16") != kernel_source_sha16():
+                        traffic_note = "stale: pmc_traffic.json was measured at kernel sources %s, current %s" % (tj.get("_kernel_src_sha16"), kernel_source_sha16())
+                    elif args.config != tj.get("_config", "b32_q4_0_b256") or custom:
+                        traffic_note = "pmc_traffic.json was measured on config %s" % tj.get("_config", "b32_q4_0_b256")
+                    else:
+                        traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                        traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2 x FETCH_SIZE + WRITE_SIZE (profiles/pmc_traffic.json)"
+                except Exception as e:   # noqa: BLE001
+                    traffic_note = "unreadable pmc_traffic.json: %s" % e
             # the binding roofline of this kernel: whichever of (algorithmic FLOPs / MFMA peak) and (algorithmic bytes / HBM peak) is
-            # the longer time.  The f32-residual GEMMs of ViT-B/32 sit at the ridge (37.7 GFLOP vs 128.6 MB per launch: 15.1 vs 16.1 us).
+            # the longer time.
             fl_l, by_l = d["flops"] / d["launches"], d["bytes"] / d["launches"]
             t_mfma, t_hbm = fl_l / (MFMA_F16_PEAK_TFLOPS * 1e12), by_l / (HBM_PEAK_GBS * 1e9)
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
@@ -204,47 +297,81 @@ def main():
             hbm_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
             main, other = (hbm_view, mfma_view) if t_hbm > t_mfma else (mfma_view, hbm_view)
             roofline = dict(main)
-            roofline.update({"kernel": dom + " (dequant + fp16 MFMA GEMM; WT,BM,BN,EPI)",
-                             "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
+            roofline.update({"kernel": dom + " (fp16 MFMA GEMM; template args as in the rocprofv3 kernel name)",
+                             "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
                              "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l,
                              "t_mfma_us": round(t_mfma * 1e6, 2), "t_hbm_us": round(t_hbm * 1e6, 2), "other_bound": other,
                              "shapes_MxNxK": sorted(d["shapes"]), "share_of_kernel_time": round(d["ms"] / total_ms, 3)})
-            kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+            kernels = {k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None}
-                       for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:14]}
+                       for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:16]}
+
+    host_api = None
+    if not args.no_host_api and rank == 0 and N == 1:
+        # the drop-in boundary itself: clip_image_batch_encode from the caller's pageable float buffers (H2D + D2H inside the call)
+        h_imgs = imgs.cpu().numpy()
+        clip.encode_images(h_imgs[: min(batch, 8)])
+        reps = 3 if batch >= 64 else 20
+        clip.encode_images(h_imgs)
+        t = time.perf_counter()
+        for _ in range(reps):
+            clip.encode_images(h_imgs)
+        host_api = round(batch * reps / (time.perf_counter() - t), 1)
+        del h_imgs
 
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and N == 1:
         from oracle import ref
         orc = ref.OracleModel(path)
-        ns = max(1, args.cpu_sample)
+        big = vc["hidden_size"] >= 1024
+        ns = args.cpu_sample if args.cpu_sample > 0 else (4 if big else 32)
+        ns = max(1, min(ns, batch))
+        nts = min(ns, n_texts)
         h_imgs = imgs[:ns].cpu().numpy()
         cores = ref.host_cores()
         t = time.perf_counter()
         want = orc.image_batch_encode(h_imgs, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=cores)
-        for ids in (texts[:ns] if n_texts else []):
-            orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=cores)
+        want_t = [orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=cores) for ids in texts[:nts]]
         cdt = time.perf_counter() - t
-        got = img_out[:ns].cpu().numpy()
-        clip.encode_images_device(imgs.data_ptr(), args.batch, img_out.data_ptr(), True)
+        # the reference harness's own form (tests/benchmark.cpp:50-51): batches of 4 images, 4 threads
+        n4 = min(ns, 4 if big else 8)
+        t = time.perf_counter()
+        for b0 in range(0, n4, 4):
+            orc.image_batch_encode(h_imgs[b0:b0 + 4], normalize=True, mode=ref.MODE_FAITHFUL, n_threads=4)
+        c4 = n4 / (time.perf_counter() - t)
+        clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True)
+        if n_texts:
+            clip.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True)
         torch.cuda.synchronize()
         got = img_out[:ns].cpu().numpy()
         cosd = 1.0 - (got * want).sum(1)
-        cpu_baseline = {"value": round((2 if n_texts else 1) * ns / cdt, 3), "unit": "embeddings/s", "cores": cores, "kind": "port",
-                        "sample": "%d images + %d texts of the same workload, oracle in ggml-faithful numerics (CPU restatement of the ggml path; ggml @dd1d575 unavailable)" % (ns, ns),
+        cpu_baseline = {"value": round((ns + nts) / cdt, 3), "unit": "embeddings/s", "cores": cores, "kind": "port",
+                        "sample": "%d images + %d texts of the same workload, oracle in ggml-faithful numerics (CPU restatement of the ggml path; ggml @dd1d575 unavailable; parity UNPINNED against ggml itself)" % (ns, nts),
+                        "chunk4_threads4_images_per_s": round(c4, 3),
+                        "chunk4_note": "reference harness form (tests/benchmark.cpp:50-51): batches of 4 images on 4 threads, %d images timed" % n4,
                         "gpu_vs_cpu_1_minus_cos_max": float(cosd.max()), "gpu_vs_cpu_1_minus_cos_mean": float(cosd.mean())}
+        if nts:
+            got_t = txt_out[:nts].cpu().numpy()
+            cosd_t = 1.0 - (got_t * np.stack(want_t)).sum(1)
+            cpu_baseline["gpu_vs_cpu_text_1_minus_cos_max"] = float(cosd_t.max())
+            cpu_baseline["gpu_vs_cpu_text_1_minus_cos_mean"] = float(cosd_t.mean())
 
     if rank == 0:
+        workload = "CLIP ViT-%s %s %s: %d images (%dx%d, vision tower)%s per GPU per step, inputs resident in HBM, %s, RCCL all-gather of final embeddings when N>1" % (
+            cfg["model"].upper(), cfg["ftype"], "two-tower" if n_texts else "vision tower only", batch, S, S,
+            (" + %d texts (1-75 tokens, text tower)" % n_texts) if n_texts else "",
+            "towers on two HIP streams (two contexts)" if overlap else ("towers back to back on one stream" if n_texts else "one stream"))
         out = {
             "metric": "image+text embeddings/sec", "value": round(value, 1), "unit": "embeddings/s", "n_gpus": N,
-            "steps": args.steps, "warmup": args.warmup, "preheat_s": args.preheat, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "steps": steps, "warmup": args.warmup, "preheat_s": args.preheat, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "CLIP ViT-%s %s two-tower: %d images (224x224, vision tower) + %d texts (1-75 tokens, text tower) per GPU per step, inputs resident in HBM, %s, RCCL all-gather of final embeddings when N>1"
-                                   % (args.model.upper(), args.ftype, args.batch, n_texts, "towers on two HIP streams (two contexts)" if overlap else "towers back to back on one stream"),
-                       "weights": "%s %s GGUF, seeded synthetic" % (args.model, args.ftype), "images_per_gpu": args.batch, "texts_per_gpu": n_texts,
+            "config": {"workload": workload, "name": args.config if not custom else "custom",
+                       "weights": "%s %s GGUF, seeded synthetic" % (cfg["model"], cfg["ftype"]), "images_per_gpu": batch, "texts_per_gpu": n_texts,
                        "text_tokens_per_gpu": int(offsets[-1]), "parallelism": "dp%d" % N},
             "images_per_s_per_gpu": round(img_rate, 1), "texts_per_s_per_gpu": round(txt_rate, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "host_api_images_per_s": host_api,
+            "roofline": roofline, "whole_step_roofline": whole, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)",
         }
         line = json.dumps(out)
         print(line, flush=True)

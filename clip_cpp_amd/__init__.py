@@ -64,7 +64,7 @@ AMD_SYMBOLS = [
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
-    "clip_amd_test_gemm", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
+    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
 
 _lib = None
@@ -147,6 +147,8 @@ def lib():
     L.clip_amd_profile_report.argtypes = [vp, C.c_char_p, i32, C.c_bool]
     L.clip_amd_test_gemm.restype = i32
     L.clip_amd_test_gemm.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32]
+    L.clip_amd_test_gemm_ex.restype = i32
+    L.clip_amd_test_gemm_ex.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32, i32, C.c_float, i32, i32, f32p]
     L.clip_amd_bench_gemm.restype = C.c_float
     L.clip_amd_bench_gemm.argtypes = [i32, C.c_int64, C.c_int64, C.c_int64, i32, i32, i32]
     L.clip_amd_test_layernorm.restype = i32

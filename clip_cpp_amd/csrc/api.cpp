@@ -519,16 +519,22 @@ int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches,
 }
 
 // ---- kernel-level test hooks ----
-int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias, const float * resid,
-                       float * y, int epilogue, int tile) {
+// Extended form: qcols / qscale (EPI_F16 Q-scale path, clip.cpp:1363) and epilogue 5 = EPI_PATCH_F32 (patch embedding:
+// row m of the GEMM lands in output row (m / Np) * T + 1 + m % Np and gets pos[1 + m % Np] added; no bias; the class-token
+// rows (b * T) are left untouched).  For epilogue 5, y is [(M / Np) * T][N] and pos is [T][N].
+int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias, const float * resid,
+                          float * y, int epilogue, int tile, int qcols, float qscale, int Np, int T, const float * pos) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); fprintf(stderr, "clip_amd_test_gemm: no HIP device\n"); return -1; }
+    if (epilogue == 5 && (Np <= 0 || T < Np + 1 || M % Np || !pos)) return -3;
     // the weight goes through the production repack path (load.cpp)
     DevWeight W;
     void * wbase = nullptr;
     if (!repack_for_test(type, w_raw, N, K, W, &wbase)) return -2;
     const int Kpad = W.Kpad;
-    DBuf dx32((size_t)M * K * 4), dx16((size_t)(M + 1) * Kpad * 2), dbias((size_t)N * 4), dres((size_t)M * N * 4), dout((size_t)M * N * 4), dout32((size_t)M * N * 4);
+    const size_t out_rows = epilogue == 5 ? (size_t)(M / Np) * T : (size_t)M;
+    DBuf dx32((size_t)M * K * 4), dx16((size_t)(M + 1) * Kpad * 2), dbias((size_t)N * 4), dres((size_t)M * N * 4), dout(out_rows * N * 4), dout32(out_rows * N * 4),
+        dpos(epilogue == 5 ? (size_t)T * N * 4 : 16);
     int rc = 0;
     hipStream_t s = nullptr;
     (void)hipMemcpy(dx32.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice);
@@ -539,10 +545,12 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
     DBuf skw((size_t)64 << 20), skc(4096 * 4);   // split-K workspace + ticket counters (as load.cpp gives the ctx)
     (void)hipMemset(skc.p, 0, 4096 * 4);
     p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)16 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
+    DBuf panel((size_t)W.Npad * W.Kpad * 2);         // fp16 panel for the 8-wave large-M kernel (quantised weights)
+    p.w16_scratch = (half_t *)panel.p; p.w16_scratch_halfs = panel.p ? (size_t)W.Npad * W.Kpad : 0;
     int epi = EPI_F32;
     switch (epilogue) {
     case 0: epi = EPI_F32; p.out = dout32.p; break;
-    case 1: epi = EPI_F16; p.out = dout.p; p.qscale = 1.0f; p.qcols = 0; break;
+    case 1: epi = EPI_F16; p.out = dout.p; p.qscale = qscale; p.qcols = qcols; break;
     case 2: epi = EPI_GELU_F16; p.out = dout.p; break;
     case 3: epi = EPI_QGELU_F16; p.out = dout.p; break;
     case 4:
@@ -551,6 +559,12 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
         p.out = dout32.p;
         p.resid = (const float *)dout32.p;
         break;
+    case 5:
+        epi = EPI_PATCH_F32;
+        (void)hipMemcpy(dpos.p, pos, (size_t)T * N * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dout32.p, y, out_rows * N * 4, hipMemcpyHostToDevice);   // caller's fill: rows the epilogue must not touch
+        p.out = dout32.p; p.Np = Np; p.T = T; p.pos = (const float *)dpos.p; p.bias = nullptr;
+        break;
     default: rc = -3;
     }
     if (rc == 0) {
@@ -558,10 +572,15 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
         if (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16)
             launch_f16_to_f32((const half_t *)dout.p, (int)N, (float *)dout32.p, (int)N, (int)M, (int)N, s);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = -4;
-        else (void)hipMemcpy(y, dout32.p, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+        else (void)hipMemcpy(y, dout32.p, out_rows * N * 4, hipMemcpyDeviceToHost);
     }
     (void)hipFree(wbase);
     return rc;
+}
+
+int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias, const float * resid,
+                       float * y, int epilogue, int tile) {
+    return clip_amd_test_gemm_ex(type, w_raw, N, K, x, M, bias, resid, y, epilogue, tile, 0, 1.0f, 0, 0, nullptr);
 }
 
 
@@ -591,7 +610,17 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     DBuf skw((size_t)64 << 20), skc(4096 * 4);
     (void)hipMemset(skc.p, 0, 4096 * 4);
     p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)16 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
-    p.debug = epilogue >> 8;   // ablation switches in the high bits (tuning only)
+    DBuf panel((size_t)W.Npad * W.Kpad * 2);
+    const bool pre = (epilogue >> 16) & 1;             // bit 16: time the GEMM alone on an already dequantised panel (per-layer form)
+    if (pre && W.wtype != W_F16 && panel.p) {
+        const DevWeight * w = &W;
+        half_t * o = (half_t *)panel.p;
+        launch_dequant(&w, &o, 1, nullptr);
+        p.w16_pre = (const half_t *)panel.p;
+    } else {
+        p.w16_scratch = (half_t *)panel.p; p.w16_scratch_halfs = panel.p ? (size_t)W.Npad * W.Kpad : 0;
+    }
+    p.debug = (epilogue >> 8) & 0xFF;   // ablation switches (tuning only)
     epilogue &= 0xFF;
     hipEvent_t a, b;
     (void)hipEventCreate(&a);

@@ -72,14 +72,57 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
         launch_gemm(p, epi, 0, ctx->stream);
         return;
     }
-    const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
-    const double by = weight_bytes(p.W) + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4);   // fused residual: read + write
-    // tag = kernel instantiation (matches the rocprofv3 kernel name gemm_dma_kernel<WT, BM, BN, EPI>) + role
     const int tile = gemm_tile_for(p.M, p.W.N);
+    const bool panel = gemm_tile_uses_panel(tile) && (p.W.wtype == W_F16 || p.w16_pre);
+    const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
+    const double wb = panel ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);   // the 8-wave kernel reads the fp16 panel of W
+    const double by = wb + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4);   // fused residual: read + write
+    // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
-    snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", p.W.wtype, tile / 1000, tile % 1000, epi, what);
+    if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
+    else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", p.W.wtype, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
     ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
     launch_gemm(p, epi, 0, ctx->stream);
+}
+
+// Large-M layers (k_gemm8.hip): the block-quantised weights of ONE layer are dequantised once into fp16 panels (L2 / Infinity-Cache
+// resident scratch, re-used by the next layer) before its four GEMMs; f16 weights are multiplied where they lie.
+struct LayerPanels { const half_t * qkv = nullptr, * o = nullptr, * ff1 = nullptr, * ff2 = nullptr; };
+
+bool ensure_panel(clip_ctx * ctx, size_t halfs) {
+    if (ctx->w16_panel_halfs >= halfs) return true;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->w16_panel) (void)hipFree(ctx->w16_panel);
+    ctx->w16_panel = nullptr;
+    ctx->w16_panel_halfs = 0;
+    if (hipMalloc((void **)&ctx->w16_panel, halfs * sizeof(half_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    ctx->w16_panel_halfs = halfs;
+    return true;
+}
+
+LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows) {
+    LayerPanels lp;
+    const DevWeight * ws[4] = {&l.qkv, &l.o, &l.ff1, &l.ff2};
+    const half_t ** slot[4] = {&lp.qkv, &lp.o, &lp.ff1, &lp.ff2};
+    const DevWeight * jw[4];
+    half_t * jo[4];
+    int nj = 0;
+    size_t need = 0;
+    for (int i = 0; i < 4; i++)
+        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N))) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
+    if (!need || !ensure_panel(ctx, need)) return lp;
+    size_t off = 0;
+    for (int i = 0; i < 4; i++)
+        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N))) {
+            jw[nj] = ws[i];
+            jo[nj] = ctx->w16_panel + off;
+            *slot[i] = jo[nj];
+            off += (size_t)ws[i]->Npad * ws[i]->Kpad;
+            nj++;
+        }
+    ProfScope ps(ctx, "dequant_layer", rows, nj, 0, 0, (double)need * 2.5625);
+    launch_dequant(jw, jo, nj, ctx->stream);
+    return lp;
 }
 
 // L x { LN1, QKV, attention, out-proj(+res), LN2, FFN-up(+act), FFN-down(+res) }   (clip.cpp:1342-1423 / :1064-1143)
@@ -90,12 +133,13 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
     for (const DevLayer & l : tw.layers) {
+        const LayerPanels lp = dequant_layer(ctx, l, rows);
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
             launch_layernorm(x, h, nullptr, 1, l.ln1_w, l.ln1_b, eps, rows, h, xn, h, nullptr, 0, s);
         }
         GemmParams p;
-        p.A = xn; p.lda = h; p.M = rows; p.W = l.qkv; p.bias = l.qkv_b; p.out = qkv; p.ldc = 3 * h;
+        p.A = xn; p.lda = h; p.M = rows; p.W = l.qkv; p.bias = l.qkv_b; p.out = qkv; p.ldc = 3 * h; p.w16_pre = lp.qkv;
         p.qscale = qscale; p.qcols = h;   // Q = (W_q x + b_q) / sqrt(d_head): scale after bias (clip.cpp:1363)
         gemm(ctx, "gemm_qkv", p, EPI_F16);
         {
@@ -107,17 +151,17 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
             }
         }
         GemmParams po;
-        po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x;
+        po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x; po.w16_pre = lp.o;
         gemm(ctx, "gemm_out", po, EPI_RESID_F32);
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
             launch_layernorm(x, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, rows, h, xn, h, nullptr, 0, s);
         }
         GemmParams p1;
-        p1.A = xn; p1.lda = h; p1.M = rows; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = mid; p1.ldc = ff;
+        p1.A = xn; p1.lda = h; p1.M = rows; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = mid; p1.ldc = ff; p1.w16_pre = lp.ff1;
         gemm(ctx, "gemm_ffn_up", p1, act);
         GemmParams p2;
-        p2.A = mid; p2.lda = ff; p2.M = rows; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = x; p2.ldc = h; p2.resid = x;
+        p2.A = mid; p2.lda = ff; p2.M = rows; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = x; p2.ldc = h; p2.resid = x; p2.w16_pre = lp.ff2;
         gemm(ctx, "gemm_ffn_down", p2, EPI_RESID_F32);
     }
     return true;

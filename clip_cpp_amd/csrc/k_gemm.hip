@@ -36,214 +36,13 @@
 // LDS->register->MFMA loop of this tile structure 1.5-1.8, tile streaming L2->LDS ~20 TB/s and not latency-bound.
 // The remaining step is a 256-wide register tile with a hand-scheduled (assembly) K loop.
 
-#include "kernels.h"
+#include "gemm_common.h"
 
 namespace clipamd {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
 
-constexpr int BK = 64;          // K step per iteration (two 32-wide quant blocks)
 constexpr int NTHREADS = 256;
-
-__device__ __forceinline__ h2 u2h(uint32_t u) { return __builtin_bit_cast(h2, u); }
-__device__ __forceinline__ uint32_t h2u(h2 h) { return __builtin_bit_cast(uint32_t, h); }
-__device__ __forceinline__ h2 splat(float x) { return (h2){(_Float16)x, (_Float16)x}; }
-
-// offset (in halfs) of 16-byte chunk c (0..7) of row r in a swizzled [rows][64] fp16 LDS tile
-__device__ __forceinline__ int lds_off(int r, int c) { return r * BK + ((c ^ (r & 7)) << 3); }
-
-// ---------------------------------------------------------------------------------------------
-// Quantised weights never touch LDS: every wave loads, per 16x32 MFMA A-fragment, ONE 32-bit word of
-// packed quants per lane (plus the block scale) straight from the block-column-major planes and
-// dequantises it in registers into the 8 fp16 values the MFMA wants.
-//
-// Packed nibble layout (load.cpp repack_rows): 32-bit word j of a block holds elements 8j..8j+7;
-// nibble p<4 is element 2p, nibble p>=4 is element 2(p-4)+1.  Hence
-//   ((w >> 4s) & 0x000F000F) = { lo half: element 2s, hi half: element 2s+1 }  (adjacent pair)
-// and OR-ing 0x6400 into each half gives the fp16 number 1024+q exactly.  Lane (row = lane&15,
-// k-group g = lane>>4) of the MFMA A operand owns elements 8g..8g+7 of the block = word g.
-// q5: fifth bits in a parallel word: bit pi = 4j+s -> element 2s of word j, bit 16+pi -> element 2s+1.
-// q8_0: bytes stored as (int8 ^ 0x80) in the order [e0,e2,e1,e3] per word: (w & 0x00FF00FF) = {e0,e1},
-//   ((w >> 8) & 0x00FF00FF) = {e2,e3}; 0x6400|u8 = 1024 + (q+128); lane g owns words 2g, 2g+1.
-// ---------------------------------------------------------------------------------------------
-template <int WT> struct WFrag;
-template <> struct WFrag<W_F16> { uint32_t q; };   // unused
-template <> struct WFrag<W_Q4_0> { uint32_t q; half_t d; };
-template <> struct WFrag<W_Q4_1> { uint32_t q; h2 dm; };
-template <> struct WFrag<W_Q5_0> { uint32_t q, h; half_t d; };
-template <> struct WFrag<W_Q5_1> { uint32_t q, h; h2 dm; };
-template <> struct WFrag<W_Q8_0> { uint32_t q, q1; half_t d; };
-
-template <int WT>
-__device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
-    uint32_t o[4] = {0, 0, 0, 0};
-    if constexpr (WT == W_F16) return __builtin_bit_cast(h8, (u32x4){f.q, 0u, 0u, 0u});
-    else
-    if constexpr (WT == W_Q8_0) {
-        const h2 scale = (h2){f.d, f.d};
-        const h2 sub = splat(1152.0f);
-        o[0] = h2u((u2h((f.q & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-        o[1] = h2u((u2h(((f.q >> 8) & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-        o[2] = h2u((u2h((f.q1 & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-        o[3] = h2u((u2h(((f.q1 >> 8) & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-    } else {
-        h2 scale, sub, add;
-        if constexpr (WT == W_Q4_0) { scale = (h2){f.d, f.d}; sub = splat(1032.0f); }
-        if constexpr (WT == W_Q5_0) { scale = (h2){f.d, f.d}; sub = splat(1040.0f); }
-        if constexpr (WT == W_Q4_1 || WT == W_Q5_1) {
-            scale = (h2){f.dm[0], f.dm[0]};
-            add = (h2){f.dm[1], f.dm[1]};
-            sub = splat(1024.0f);
-        }
-        uint32_t hb = 0;
-        if constexpr (WT == W_Q5_0 || WT == W_Q5_1) hb = (uint32_t)(((uint64_t)f.h << 4) >> (4 * g));  // pair bits of word g at 4+s / 20+s
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            uint32_t u = ((f.q >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
-            if constexpr (WT == W_Q5_0 || WT == W_Q5_1) u |= (hb >> s) & 0x00100010u;
-            h2 v = u2h(u) - sub;  // exact small integer
-            if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
-            else v = v * scale;
-            o[s] = h2u(v);
-        }
-    }
-    return __builtin_bit_cast(h8, (u32x4){o[0], o[1], o[2], o[3]});
-}
-
-// One whole 32-weight block per thread (LDS-staged path): the 4 (q8_0: 8) packed words + fifth bits + scale.
-template <int WT> struct RawBlock { u32x4 qs, qs1; uint32_t h; half_t d; h2 dm; };
-
-template <int WT>
-__device__ __forceinline__ void load_block(RawBlock<WT> & r, const DevWeight & W, size_t idx) {
-    if constexpr (WT == W_Q8_0) {
-        const u32x4 * q = (const u32x4 *)W.qs + idx * 2;
-        r.qs = q[0];
-        r.qs1 = q[1];
-    } else if constexpr (WT != W_F16) {
-        r.qs = ((const u32x4 *)W.qs)[idx];
-    }
-    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) r.h = ((const uint32_t *)W.qh)[idx];
-    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) r.dm = ((const h2 *)W.dm)[idx];
-    else if constexpr (WT != W_F16) r.d = ((const half_t *)W.dm)[idx];
-}
-
-// word j (8 weights) of a block as a register fragment
-template <int WT>
-__device__ __forceinline__ WFrag<WT> block_word(const RawBlock<WT> & r, int j) {
-    WFrag<WT> f;
-    if constexpr (WT == W_Q8_0) {
-        const uint32_t w[8] = {r.qs[0], r.qs[1], r.qs[2], r.qs[3], r.qs1[0], r.qs1[1], r.qs1[2], r.qs1[3]};
-        f.q = w[2 * j];
-        f.q1 = w[2 * j + 1];
-    } else {
-        f.q = r.qs[j];
-    }
-    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) f.h = r.h;
-    if constexpr (WT == W_Q4_1 || WT == W_Q5_1) f.dm = r.dm;
-    else if constexpr (WT != W_F16) f.d = r.d;
-    return f;
-}
-
-// Activations of the FFN-up epilogue.  The result is rounded to fp16 right after, so the reciprocal is the hardware
-// v_rcp_f32 (1 ulp) instead of an IEEE division sequence (~10 instructions per element; at 96 outputs per thread the
-// epilogue was ~6 % of a K = 768 tile's time).  The reference evaluates both through fp16 lookup tables.
-__device__ __forceinline__ float gelu_tanh(float x) {
-    // ggml_gelu_f32: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)));  0.5 (1 + tanh(u)) = 1 - 1/(exp(2u) + 1)
-    const float u = 0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x);
-    const float e = __expf(2.0f * u);
-    return x - x * __builtin_amdgcn_rcpf(e + 1.0f);
-}
-__device__ __forceinline__ float gelu_quick(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
-
-// ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15).
-// nbase / mbase: first weight row / activation row of this wave's sub-tile.
-template <int EPI, int TN, int TM>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp) {
-    const int N = p.W.N;
-#pragma unroll
-    for (int a = 0; a < TN; a++) {
-        const int n = nbase + a * 16 + fgrp * 4;
-        if (n >= N) continue;
-        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PATCH_F32 && p.bias) bias = *(const f4 *)(p.bias + n);
-#pragma unroll
-        for (int b = 0; b < TM; b++) {
-            const int m = mbase + b * 16 + frow;
-            if (m >= p.M) continue;
-            f4 v = acc[a][b] + bias;
-            if constexpr (EPI == EPI_F32) {
-                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                const f4 r = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
-                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r + v;
-            } else if constexpr (EPI == EPI_PATCH_F32) {
-                const int img = m / p.Np, pp = m % p.Np;
-                const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
-                *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
-            } else {
-                if constexpr (EPI == EPI_F16) {
-                    if (n < p.qcols) v = v * p.qscale;
-                } else if constexpr (EPI == EPI_GELU_F16) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
-                } else if constexpr (EPI == EPI_QGELU_F16) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
-                }
-                const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
-                const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
-                *(uint2 *)((half_t *)p.out + (size_t)m * p.ldc + n) = make_uint2(h2u(lo), h2u(hi));
-            }
-        }
-    }
-}
-
-// ---- f16-output epilogue staged through LDS (qkv / FFN-up): written straight from the accumulator layout, a wave store
-// covers 16 rows x 32 B — quarter cache lines, measured ~3 TB/s and 27-31 % of those GEMMs' time (profiles/).  Instead each
-// wave parks its (BM/2) x (BN/2) fp16 sub-tile in its own LDS region (rows padded to 136 B: conflict-free 8-byte writes)
-// and re-reads it row-contiguous, so every global store instruction writes 8 full 128-byte lines.
-// Requires BN/2 == 64, the whole n range of the wave inside N, and a 16-byte aligned output row (ldc % 8 == 0).
-template <int EPI, int TN, int TM>
-__device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
-                                                         half_t * stage, int lane) {
-    constexpr int RS = 68;                                     // halfs per staged row (64 + 4 pad = 136 B)
-#pragma unroll
-    for (int a = 0; a < TN; a++) {
-        const int n = nbase + a * 16 + fgrp * 4;
-        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *(const f4 *)(p.bias + n);
-#pragma unroll
-        for (int b = 0; b < TM; b++) {
-            f4 v = acc[a][b] + bias;
-            if constexpr (EPI == EPI_F16) {
-                if (n < p.qcols) v = v * p.qscale;
-            } else if constexpr (EPI == EPI_GELU_F16) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
-            } else if constexpr (EPI == EPI_QGELU_F16) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
-            }
-            const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
-            const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
-            *(uint2 *)(stage + (b * 16 + frow) * RS + a * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
-        }
-    }
-    // the region is private to this wave: no barrier, the LDS writes are ordered before the reads by lgkmcnt
-    const int rrow = lane >> 3, rchunk = lane & 7;
-#pragma unroll
-    for (int i = 0; i < TM * 2; i++) {
-        const int ml = i * 8 + rrow;
-        const int m = mbase + ml;
-        const u32x4 v = *(const u32x4 *)(stage + ml * RS + rchunk * 8);
-        if (m < p.M) *(u32x4 *)((half_t *)p.out + (size_t)m * p.ldc + nbase + rchunk * 8) = v;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA variant: fp16 tiles (X always, W when the weights are f16) go HBM/L2 -> LDS with
@@ -595,6 +394,13 @@ int pick_tile(int M, int N) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
     if (wgs(128, 128) < 100) return wgs(64, 128) >= 256 ? 64128 : 64064;
+    // large M: the 8-wave 160 x 256 kernel (k_gemm8.hip), one workgroup per CU -> rounds of 256 tiles
+    {
+        const int t8 = wgs(160, 256);
+        const float rounds = (float)t8 / 256.f;
+        const float eff = rounds / ceilf(rounds);          // fraction of the last round's CUs that have work
+        if (t8 >= 200 && eff >= 0.75f) return 160256;
+    }
     int best = 128128;
     float best_cost = 0.f;
     const int cand[4] = {128, 160, 192, 64};
@@ -646,6 +452,24 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
     int ksplit = tile / 1000000;        // explicit: ksplit * 1000000 + BM * 1000 + BN  (no prefix = no split)
     tile %= 1000000;
     if (heuristic) tile = pick_tile(p.M, p.W.N);
+    if (gemm_tile_uses_panel(tile)) {
+        // 8-wave large-M kernel: fp16 x fp16 from a row-major panel of W; block-quantised weights are dequantised into it first
+        // (unless the caller already did, per layer)
+        const half_t * panel = p.W.wtype == W_F16 ? (const half_t *)p.W.w16 : p.w16_pre;
+        if (!panel && p.w16_scratch && p.w16_scratch_halfs >= (size_t)p.W.Npad * p.W.Kpad) {
+            const DevWeight * w = &p.W;
+            half_t * o = p.w16_scratch;
+            launch_dequant(&w, &o, 1, stream);
+            panel = p.w16_scratch;
+        }
+        if (panel) {
+            p.W.wtype = W_F16;
+            p.W.w16 = panel;
+            launch_gemm8(p, epilogue, tile / 32000, stream);
+            return;
+        }
+        tile = 160128;   // no panel available: the fused 4-wave kernel
+    }
     const int bm = tile / 1000, bn = tile % 1000;
     const int tiles = ((p.M + bm - 1) / bm) * ((p.W.N + bn - 1) / bn), nk = p.W.Kpad / BK;
     if (heuristic) ksplit = pick_ksplit(tiles, nk);

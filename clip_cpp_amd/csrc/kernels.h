@@ -74,12 +74,26 @@ struct GemmParams {
     unsigned * sk_cnt = nullptr;
     int sk_cnt_n = 0;
     int ksplit = 1;
+    // large-M path (k_gemm8.hip): fp16 panel of a block-quantised W ([Npad][Kpad] row-major).  w16_pre != null: the panel was
+    // already filled for this launch (per-layer dequantisation, forward.cpp); else launch_gemm fills w16_scratch
+    // (>= Npad * Kpad halfs) itself when it picks that path; with neither, quantised weights stay on the fused 4-wave kernel.
+    const half_t * w16_pre = nullptr;
+    half_t * w16_scratch = nullptr;
+    size_t w16_scratch_halfs = 0;
     int debug = 0;   // ablation switches, honoured only by -DCLIPAMD_ABLATION tuning builds (scripts/build_variant.sh): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
 };
 
-// tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64)
+// tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64;
+// BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
 int gemm_tile_for(int M, int N);   // the tile (BM*1000+BN) the heuristic picks for this shape
+inline bool gemm_tile_uses_panel(int tile) { return tile % 1000 == 256; }   // the shape runs on the 8-wave kernel (fp16 W panel)
+
+// k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
+void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);
+// dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)
+struct DequantJobs { DevWeight W[4]; half_t * out[4]; int blk_end[4]; int n = 0; };
+void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, hipStream_t stream);
 
 // LayerNorm over rows of h floats (ggml_norm + mul + add, reference clip.cpp:1350-1355).
 // Row r reads x[in_rows[r]] when in_rows != nullptr, else x[r * in_row_mul] (strided gather, e.g. the

@@ -413,6 +413,7 @@ void free_model(clip_ctx * ctx) {
         if (ctx->io_in) (void)hipFree(ctx->io_in);
         if (ctx->io_out) (void)hipFree(ctx->io_out);
         if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
+        if (ctx->w16_panel) (void)hipFree(ctx->w16_panel);
         if (ctx->sk_ws) (void)hipFree(ctx->sk_ws);
         if (ctx->sk_cnt) (void)hipFree(ctx->sk_cnt);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -89,6 +89,9 @@ struct clip_ctx {
     size_t sk_ws_floats = 0;
     unsigned * sk_cnt = nullptr;
     int sk_cnt_n = 0;
+    // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
+    clipamd::half_t * w16_panel = nullptr;
+    size_t w16_panel_halfs = 0;
 
     // profiling (HIP events on the ctx stream)
     bool profiling = false;

@@ -89,6 +89,14 @@ int clip_amd_profile_report(struct clip_ctx * ctx, char * buf, int cap, bool res
  *           4 residual: Y = resid + X.W^T + bias (f32).  tile: 0 auto, else BM*1000+BN. */
 int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M,
                        const float * bias, const float * resid, float * y, int epilogue, int tile);
+/* Same, plus the two epilogue features the plain hook cannot reach: epilogue 1 with qcols / qscale (columns n < qcols
+ * are multiplied by qscale AFTER the bias: the 1/sqrt(d_head) Q scale of the fused q/k/v projection, reference
+ * clip.cpp:1363) and epilogue 5 = patch embedding (reference clip.cpp:1309-1331): GEMM row m -> output row
+ * (m / Np) * T + 1 + m % Np with pos[1 + m % Np] added, no bias; y is [(M / Np) * T][N] and is uploaded first so that
+ * untouched rows (the class-token rows) keep the caller's fill; pos is [T][N]. */
+int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M,
+                          const float * bias, const float * resid, float * y, int epilogue, int tile,
+                          int qcols, float qscale, int Np, int T, const float * pos);
 /* Average device time (microseconds, HIP events) of one GEMM shape through the production kernel on random
  * weights of ggml type `type`; < 0 on error.  Used by scripts/gemm_bench.py for kernel A/B work. */
 float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters);

@@ -19,11 +19,13 @@ SHAPES = [  # (name, M, N, K, epi)
     ("b1.qkv", 50, 2304, 768, 1), ("b1.out", 50, 768, 768, 4), ("b1.up", 50, 3072, 768, 3), ("b1.down", 50, 768, 3072, 4),
     ("b32.b32.qkv", 1600, 2304, 768, 1), ("b32.b32.out", 1600, 768, 768, 4),
     ("txt.qkv", 10290, 1536, 512, 1), ("txt.out", 10290, 512, 512, 4), ("txt.up", 10290, 2048, 512, 3), ("txt.down", 10290, 512, 2048, 4),
+    ("l14.qkv", 65792, 3072, 1024, 1), ("l14.out", 65792, 1024, 1024, 4),
 ]
 tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
 types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
 only = [a for a in sys.argv[1:] if "." in a]
 debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]
+PRE = (1 << 16) if "pre" in sys.argv[1:] else 0   # 8-wave kernel: time the GEMM alone on an already dequantised fp16 panel (per-layer form)
 if "blas" in sys.argv[1:]:
     # yardstick: the vendor library (hipBLASLt / rocBLAS through torch) on the same shapes, plain f16 x f16 -> f16, no epilogue
     for name, M, N, K, epi in SHAPES:
@@ -49,6 +51,6 @@ for tname in types:
         row = []
         for tile in tiles:
             for dbg in debug:
-                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8), tile, 20)
+                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8) | PRE, tile, 20)
                 row.append("%7d%s: %8.1f us %7.1f TF" % (tile, ("/d%d" % dbg) if dbg else "", us, 2.0 * M * N * K / us / 1e6 if us > 0 else -1))
         print("%-5s %-14s M=%6d N=%5d K=%5d | %s" % (tname, name, M, N, K, " | ".join(row)), flush=True)

@@ -28,6 +28,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert rf["other_bound"]["bound"] != rf["bound"] and (rf["t_hbm_us"] > rf["t_mfma_us"]) == (rf["bound"] == "hbm")
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["gpu_vs_cpu_1_minus_cos_max"] <= 1e-3
+    assert cb["gpu_vs_cpu_text_1_minus_cos_max"] <= 1e-3          # the text half of the metric is checked against the oracle too
+    assert cb["chunk4_threads4_images_per_s"] > 0                 # reference harness form (tests/benchmark.cpp:50-51)
+    ws = d["whole_step_roofline"]
+    assert ws["bound"] in ("mfma", "hbm") and 0 < ws["frac"] <= 1.0 and ws["algorithmic_flops_per_step"] > 0
+    assert d["host_api_images_per_s"] > 0 and d["config"]["name"] == "custom"
+    assert "traffic" in rf and "traffic_note" in rf
 
 
 def test_graft_entry_smoke_runs():

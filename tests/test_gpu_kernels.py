@@ -81,7 +81,7 @@ def test_gemm_all_weight_types_vs_dequant_reference(L, tname, shape):
     assert rel < (5e-4 if tname in ("f16", "f32") else 2e-2), rel
 
 
-@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128])
+@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128, 96256, 128256, 160256])
 @pytest.mark.parametrize("tname", ["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     """Every tile shape accumulates each output in the same k order -> identical bits; also exercises M/N edges."""
@@ -199,3 +199,128 @@ def test_attention_vs_reference(L, cfg):
     assert np.all(np.isfinite(out))
     err = np.abs(out - want).max()
     assert err < 4e-3, (cfg, err)
+
+
+def run_gemm_ex(L, tid, raw, N, K, X, bias=None, epi=0, tile=0, qcols=0, qscale=1.0, Np=0, T=0, pos=None, y=None):
+    M = X.shape[0]
+    if y is None:
+        y = np.full((M, N), np.nan, dtype=np.float32)
+    rc = L.clip_amd_test_gemm_ex(tid, raw.ctypes.data_as(C.c_void_p), N, K, _fp(X), M, _fp(bias) if bias is not None else None, None,
+                                 _fp(y), epi, tile, qcols, qscale, Np, T, _fp(pos) if pos is not None else None)
+    assert rc == 0, "clip_amd_test_gemm_ex rc=%d" % rc
+    return y
+
+
+# The GEMM shapes of the TEXT tower at the BASELINE workload (256 ragged texts = 10290 token rows; ViT-B/32 text: h=512, ff=2048;
+# ViT-L/14 text: h=768, ff=3072) plus odd row counts: 192-row tiles, N = 512 ... 3072, K = 512 ... 3072 (reference clip.cpp:1079-1136).
+TEXT_SHAPES = [(10290, 1536, 512), (10290, 2048, 512), (10290, 512, 2048), (10290, 512, 512),
+               (1531, 512, 512), (769, 2048, 512), (4099, 2304, 768), (2051, 768, 3072)]
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "f16"])
+@pytest.mark.parametrize("shape", TEXT_SHAPES)
+def test_gemm_text_tower_shapes_vs_dequant_reference(L, tname, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(hash((tname, shape, "text")) % (2 ** 31))
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    Wd = ref.dequantize(tid, raw, N, K).astype(np.float64)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    Xh = _h(X).astype(np.float64)
+    want = Xh @ Wd.T + bias
+    bound = 1.0e-3 * (np.abs(Xh) @ np.abs(Wd).T) + 1e-5
+    for tile in (0, 192128, 128128, 160256):               # heuristic choice, the 192-row tile, a square tile, the 8-wave large-M kernel
+        y = run_gemm(L, tid, raw, N, K, X, bias=bias, epi=0, tile=tile)
+        assert np.all(np.isfinite(y))
+        bad = np.argwhere(np.abs(y - want) > bound)
+        assert bad.size == 0, "tile %d: %d/%d bad, first %s got %g want %g" % (tile, len(bad), y.size, bad[0], y[tuple(bad[0])], want[tuple(bad[0])])
+        if tile == 0:
+            base = y
+        else:
+            assert np.array_equal(y, base), "tile %d differs bitwise from the heuristic tile" % tile
+    # the residual epilogue (out-proj / FFN-down, f32 stream) at the same shape
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    yr = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=4)
+    assert np.all(np.abs(yr - (want + resid)) <= bound + 1e-6 * np.abs(resid))
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "q5_1", "f16"])
+@pytest.mark.parametrize("M,N,K,qcols", [(203, 384, 128, 128), (1600, 2304, 768, 768), (77, 1536, 512, 512), (130, 192, 64, 100)])
+def test_gemm_f16_epilogue_q_scale_columns(L, tname, M, N, K, qcols):
+    """EPI_F16 with qcols > 0: columns n < qcols carry (acc + bias) * qscale (scale AFTER the bias, reference clip.cpp:1363),
+    the others acc + bias.  Elementwise bound; a wrong scale on a single column fails."""
+    rng = np.random.default_rng(M * 7 + N)
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K) * 4)
+    Wd = ref.dequantize(tid, raw, N, K).astype(np.float64)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    qscale = 0.125 if qcols != 100 else 0.3
+    Xh = _h(X).astype(np.float64)
+    lin = Xh @ Wd.T + bias
+    want = lin.copy()
+    want[:, :qcols] *= np.float32(qscale)
+    y = run_gemm_ex(L, tid, raw, N, K, X, bias=bias, epi=1, qcols=qcols, qscale=qscale)
+    # fp16 output: half an ulp of the result + the dequant-product bound
+    bound = 1.0e-3 * (np.abs(Xh) @ np.abs(Wd).T + np.abs(bias)) + np.abs(want) * 2.0 ** -10 + 1e-4
+    bad = np.argwhere(np.abs(y - want) > bound)
+    assert bad.size == 0, "%d bad, first %s got %g want %g" % (len(bad), bad[0], y[tuple(bad[0])], want[tuple(bad[0])])
+    # the boundary column pair must differ by the scale: column qcols-1 scaled, column qcols not
+    np.testing.assert_allclose(y[:, qcols - 1], want[:, qcols - 1], atol=float(bound[:, qcols - 1].max()))
+    np.testing.assert_allclose(y[:, qcols], want[:, qcols], atol=float(bound[:, qcols].max()))
+
+
+@pytest.mark.parametrize("B,G,h,P", [(3, 7, 768, 32), (2, 16, 1024, 14), (5, 4, 64, 8), (33, 7, 768, 32)])
+def test_gemm_patch_embedding_epilogue(L, B, G, h, P):
+    """EPI_PATCH_F32 (patch embedding, reference clip.cpp:1309-1331): GEMM row m = (image, patch) is scattered to token row
+    image * T + 1 + patch and gets position_embd[1 + patch] added; no bias; class-token rows are not written."""
+    rng = np.random.default_rng(B * 100 + G)
+    Np, T, K = G * G, G * G + 1, 3 * P * P
+    Wf = (rng.standard_normal((h, K)) * 0.02).astype(np.float32)
+    raw = ref.quantize(1, Wf)                               # patch kernel is always f16
+    Wd = ref.dequantize(1, raw, h, K).astype(np.float64)
+    X = rng.standard_normal((B * Np, K)).astype(np.float32)
+    pos = (rng.standard_normal((T, h)) * 0.02).astype(np.float32)
+    y = np.full((B * T, h), 777.0, dtype=np.float32)
+    y = run_gemm_ex(L, 1, raw, h, K, X, epi=5, Np=Np, T=T, pos=pos, y=y)
+    Xh = _h(X).astype(np.float64)
+    lin = Xh @ Wd.T
+    bound = 1.0e-3 * (np.abs(Xh) @ np.abs(Wd).T) + 1e-5
+    y3 = y.reshape(B, T, h)
+    assert np.all(y3[:, 0, :] == 777.0)                     # class rows untouched
+    want = lin.reshape(B, Np, h) + pos[None, 1:, :]
+    assert np.all(np.abs(y3[:, 1:, :] - want) <= bound.reshape(B, Np, h))
+
+
+@pytest.mark.parametrize("tile", [96256, 128256, 160256])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 448, 1024])
+@pytest.mark.parametrize("tname,epi", [("f16", 0), ("q4_0", 4), ("q5_1", 1), ("q8_0", 2)])
+def test_gemm8_ring_lengths_and_epilogues_match_the_4_wave_kernel_bitwise(L, tile, K, tname, epi):
+    """8-wave large-M kernel (k_gemm8.hip): 1 ... 16 K-tiles through the 3-stage LDS ring (prologue / steady state / tail of the
+    counted-vmcnt pipeline), M and N edges inside a tile, block-quantised weights through the dequantised fp16 panel, every
+    epilogue family: bit-identical to the 64x64 tile of the 4-wave kernel (same MFMA, same k order, same dequant arithmetic)."""
+    rng = np.random.default_rng(K * 13 + tile)
+    M, N = 333, 576
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K) * 3)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + 64064)   # unsplit 64x64 tiles
+    y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
+    assert np.all(np.isfinite(y))
+    assert np.array_equal(base, y), np.abs(base - y).max()
+    y2 = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
+    assert np.array_equal(y, y2)
+
+
+def test_gemm8_many_tiles_race_screen(L):
+    """More workgroups than CUs, several rounds, repeated: a ring / barrier race shows up as a rare wrong tile."""
+    rng = np.random.default_rng(5)
+    M, N, K = 4000, 1024, 768
+    raw = ref.quantize(1, _weights(rng, N, K))
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    base = run_gemm(L, 1, raw, N, K, X, epi=0, tile=128128)
+    for _ in range(6):
+        assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=160256), base)

@@ -58,6 +58,61 @@ def test_two_tower_parity_small_models(gpu, fixture_cache, config, ftype):
     clip.close()
 
 
+def _ragged_text_batch(n, npos, seed):
+    """n ragged texts (BOS + ids + EOS) whose token counts cover 1 ... npos: a bare BOS (1 token), BOS+EOS (2), the longest
+    legal sequence (npos), duplicates of one length, the rest seeded uniform."""
+    rng = np.random.default_rng(seed)
+    lens = [1, 2, npos, npos, 9, 9, 9, npos - 1, 3] + [int(v) for v in rng.integers(2, npos + 1, size=n - 9)]
+    out = []
+    for ln in lens:
+        if ln == 1:
+            out.append(np.array([49406], np.int32))
+            continue
+        ids = rng.integers(0, fixtures.N_VOCAB - 2, size=ln - 2).astype(np.int32)
+        out.append(np.concatenate([[49406], ids, [49407]]).astype(np.int32))
+    return out
+
+
+@pytest.mark.parametrize("config,ftype,n_texts", [("b32", "q4_0", 72), ("l14", "f16", 64), ("b32", "q8_0", 16), ("l14", "q5_1", 12)])
+def test_text_tower_parity_at_model_shape(gpu, fixture_cache, config, ftype, n_texts):
+    """Row a13: clip_text_encode at the REAL text-tower shapes (ViT-B/32: h=512, ff=2048, 8 heads; ViT-L/14: h=768, ff=3072,
+    12 heads; 12 layers, 77 positions, q4_0 / f16 token_embd) against the oracle in ggml-faithful numerics, reference
+    clip.cpp:1016-1233: token/position gather :1059-1061, causal mask :1101, last-row pooling :1154-1155.  One ragged batch
+    of >= 64 texts with 1 ... 77 tokens (incl. a 77-token text and duplicate lengths); every text is also encoded alone."""
+    p = fixtures.cached_model(fixture_cache, config, ftype, text=True, vision=False)
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    npos = clip.text_config["num_positions"]
+    assert npos == 77
+    texts = _ragged_text_batch(n_texts, npos, seed=1000 + n_texts)
+    assert max(len(t) for t in texts) == 77 and min(len(t) for t in texts) == 1
+    for normalize in (True, False):
+        batch = clip.encode_texts(texts, normalize=normalize)
+        assert batch.shape == (n_texts, clip.text_config["projection_dim"]) and np.all(np.isfinite(batch))
+        want = np.stack([orc.text_encode(ids, normalize=normalize, mode=ref.MODE_FAITHFUL) for ids in texts])
+        d = one_minus_cos(batch, want)
+        assert np.all(d <= TOL[ftype]), (config, ftype, normalize, float(d.max()), int(d.argmax()), len(texts[int(d.argmax())]))
+        if not normalize:
+            np.testing.assert_allclose(np.linalg.norm(batch, axis=1), np.linalg.norm(want, axis=1), rtol=2e-2)
+    batch = clip.encode_texts(texts, normalize=True)
+    assert np.array_equal(batch, clip.encode_texts(texts, normalize=True))                      # deterministic
+    for i in list(range(9)) + [n_texts - 1]:
+        single = np.asarray(clip.encode_text(list(texts[i]), normalize=True), dtype=np.float32)
+        assert one_minus_cos(single, want_n(orc, texts[i])) <= TOL[ftype], i
+        # batch row == the text alone, up to the fp32 re-association of a different GEMM schedule (split-K at small M)
+        assert one_minus_cos(single, batch[i]) <= 1e-6, (i, len(texts[i]))
+        np.testing.assert_allclose(batch[i], single, atol=3e-4)
+    # a different batch composition around the same texts gives the same rows (no cross-text leakage through the ragged layout)
+    perm = np.random.default_rng(3).permutation(n_texts)
+    shuffled = clip.encode_texts([texts[j] for j in perm], normalize=True)
+    assert np.all(one_minus_cos(shuffled, batch[perm]) <= 1e-6)
+    np.testing.assert_allclose(shuffled, batch[perm], atol=3e-4)
+    clip.close()
+
+
+def want_n(orc, ids):
+    return orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL)
+
+
 def test_gelu_models_and_vision_only_text_only(gpu, fixture_cache):
     p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", use_gelu=True)
     clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
