@@ -59,7 +59,8 @@ API_SYMBOLS = [
     "ggml_time_init", "ggml_time_us", "ggml_time_ms",
 ]
 AMD_SYMBOLS = [
-    "clip_amd_device_count", "clip_amd_model_load", "clip_amd_ctx_device", "clip_amd_set_stream",
+    "clip_amd_device_count", "clip_amd_model_load", "clip_amd_model_load_multi", "clip_amd_ctx_device_count", "clip_amd_shard_bounds",
+    "clip_amd_gathered_embeddings", "clip_amd_ctx_device", "clip_amd_set_stream",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
@@ -88,6 +89,13 @@ def lib():
     L.clip_model_load.argtypes = [C.c_char_p, i32]
     L.clip_amd_model_load.restype = vp
     L.clip_amd_model_load.argtypes = [C.c_char_p, i32, i32]
+    L.clip_amd_model_load_multi.restype = vp
+    L.clip_amd_model_load_multi.argtypes = [C.c_char_p, i32, i32]
+    L.clip_amd_ctx_device_count.restype = i32
+    L.clip_amd_ctx_device_count.argtypes = [vp]
+    L.clip_amd_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.clip_amd_gathered_embeddings.restype = vp
+    L.clip_amd_gathered_embeddings.argtypes = [vp, i32]
     L.clip_free.argtypes = [vp]
     L.clip_get_text_hparams.restype = C.POINTER(ClipTextHparams)
     L.clip_get_text_hparams.argtypes = [vp]
@@ -174,10 +182,12 @@ def _struct_to_dict(s):
 class Clip:
     """Same surface as the reference binding's `Clip` (clip.py:215-424), minus the HF-hub downloader."""
 
-    def __init__(self, model_path_or_repo_id, verbosity=0, device=None):
+    def __init__(self, model_path_or_repo_id, verbosity=0, device=None, n_devices=None):
         L = lib()
         path = os.fsencode(model_path_or_repo_id)
-        if device is None:
+        if n_devices is not None:       # single process, replicas on n_devices GPUs, batch sharding + RCCL all-gather behind the C ABI
+            self.ctx = L.clip_amd_model_load_multi(path, verbosity, int(n_devices))
+        elif device is None:
             self.ctx = L.clip_model_load(path, verbosity)
         else:
             self.ctx = L.clip_amd_model_load(path, verbosity, int(device))
@@ -317,7 +327,11 @@ class Clip:
             raise RuntimeError("clip_amd_image_batch_preprocess_device failed (see stderr)")
         self.synchronize()   # `keep` (the host pixels) must outlive the copy into the pinned blob — it does: the copy is synchronous
 
-    def encode_images(self, imgs, normalize=True):
+    @property
+    def n_devices(self):
+        return lib().clip_amd_ctx_device_count(self.ctx)
+
+    def encode_images(self, imgs, normalize=True, n_threads=None):
         """float32 [B,S,S,3] preprocessed images (host) -> float32 [B,proj] via clip_image_batch_encode."""
         imgs = np.ascontiguousarray(imgs, dtype=np.float32)
         B, S = imgs.shape[0], imgs.shape[1]
@@ -326,7 +340,7 @@ class Clip:
             arr[b] = ClipImageF32(S, imgs.shape[2], imgs[b].ctypes.data_as(C.POINTER(C.c_float)), imgs[b].size)
         batch = ClipImageF32Batch(C.cast(arr, C.POINTER(ClipImageF32)), B)
         out = np.empty((B, self.vision_config["projection_dim"]), dtype=np.float32)
-        if not lib().clip_image_batch_encode(self.ctx, 1, C.byref(batch), _fp(out), normalize):
+        if not lib().clip_image_batch_encode(self.ctx, n_threads or min(16, os.cpu_count() or 1), C.byref(batch), _fp(out), normalize):
             raise RuntimeError("clip_image_batch_encode failed (see stderr)")
         return out
 
@@ -393,3 +407,10 @@ def gguf_inspect(path):
 
 def quantize(fname_inp, fname_out, itype):
     return bool(lib().clip_model_quantize(os.fsencode(fname_inp), os.fsencode(fname_out), int(itype)))
+
+
+def shard_bounds(total, n_devices, device_index):
+    """(lo, hi, rows_per_device) of the multi-GPU clip_image_batch_encode (clip_amd_shard_bounds; pure arithmetic)."""
+    lo, hi, per = C.c_int(), C.c_int(), C.c_int()
+    lib().clip_amd_shard_bounds(total, n_devices, device_index, C.byref(lo), C.byref(hi), C.byref(per))
+    return lo.value, hi.value, per.value

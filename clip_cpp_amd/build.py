@@ -22,7 +22,7 @@ GGML_STUB = os.path.join(HERE, "libggml.so")
 ARCH = "gfx950"
 
 HOST_SOURCES = ["gguf.cpp", "quant.cpp", "load.cpp", "forward.cpp", "tokenizer.cpp", "preprocess.cpp", "image_io.cpp",
-                "jpeg_decode.cpp", "api.cpp"]
+                "jpeg_decode.cpp", "host_pipeline.cpp", "api.cpp"]
 HIP_SOURCES = ["k_attn.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip"]
 GEMM_WTYPES = [0, 1, 2, 3, 4, 5]
 
@@ -83,7 +83,7 @@ def build(force=False, verbose=False):
                 if verbose and out.strip():
                     print(out)
     if force or jobs or _newer(LIB, objs):
-        _run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread"])
+        _run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread", "-ldl"])
     stub_src = os.path.join(CSRC, "ggml_stub.c")
     if force or _newer(GGML_STUB, [stub_src]):
         _run(["gcc", "-O2", "-fPIC", "-shared", "-o", GGML_STUB, stub_src])

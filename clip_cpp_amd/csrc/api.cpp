@@ -69,8 +69,33 @@ int clip_amd_device_count(void) {
 int clip_amd_ctx_device(const struct clip_ctx * ctx) { return ctx ? ctx->device : -1; }
 void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream) {
     if (!ctx || ctx->device < 0) return;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next == ctx->stream) return;
+    // A context owns ONE workspace (activations, staging buffers, split-K tickets): work queued on the new stream must not
+    // start before what is still queued on the previous one has finished.
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->ev_stream_switch) (void)hipEventCreateWithFlags(&ctx->ev_stream_switch, hipEventDisableTiming);
+    if (ctx->ev_stream_switch && hipEventRecord(ctx->ev_stream_switch, ctx->stream) == hipSuccess &&
+        hipStreamWaitEvent(next, ctx->ev_stream_switch, 0) == hipSuccess) {
+    } else {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    ctx->stream = next;
 }
+struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, int n_devices) {
+    if (!fname) return nullptr;
+    return multi_load(fname, verbosity, n_devices);
+}
+int clip_amd_ctx_device_count(const struct clip_ctx * ctx) { return ctx ? multi_device_count(ctx) : 0; }
+void clip_amd_shard_bounds(int total, int n_devices, int device_index, int * lo, int * hi, int * rows_per_device) {
+    int l = 0, h = 0, p = 0;
+    if (n_devices > 0 && device_index >= 0 && device_index < n_devices && total >= 0) multi_shard(total, n_devices, device_index, &l, &h, &p);
+    if (lo) *lo = l;
+    if (hi) *hi = h;
+    if (rows_per_device) *rows_per_device = p;
+}
+const float * clip_amd_gathered_embeddings(const struct clip_ctx * ctx, int device_index) { return ctx ? multi_gathered(ctx, device_index) : nullptr; }
 void clip_amd_synchronize(struct clip_ctx * ctx) {
     if (ctx && ctx->device >= 0) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
 }
@@ -147,23 +172,21 @@ bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, 
         }
     }
     (void)hipSetDevice(ctx->device);
-    const int chunk = 256;
-    const int cmax = std::min(B, chunk);
-    if (!ensure_io(ctx, per * 4 * cmax, (size_t)proj * 4 * cmax)) {
+    const int nt = std::max(1, n_threads);
+    if (ctx->multi && B >= 2 * multi_device_count(ctx)) {
+        // sharded over the devices of a clip_amd_model_load_multi context: ceil(B/G) images per device, one RCCL all-gather
+        const bool mok = multi_image_batch_encode(ctx, imgs->data, B, vec, normalize, nt);
+        if (!mok) fprintf(stderr, "clip_image_batch_encode: multi-device encode failed: %s\n", hipGetErrorString(hipGetLastError()));
+        return mok;
+    }
+    if (!ensure_io(ctx, 16, (size_t)proj * 4 * B)) {
         fprintf(stderr, "clip_image_batch_encode: out of device memory\n");
         return false;
     }
-    void * d_in = ctx->io_in;
-    void * d_out = ctx->io_out;
-    bool ok = true;
-    for (int b0 = 0; b0 < B && ok; b0 += chunk) {
-        const int Bc = std::min(chunk, B - b0);
-        for (int b = 0; b < Bc; b++)
-            ok = ok && hipMemcpyAsync((float *)d_in + per * b, imgs->data[b0 + b].data, per * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-        ok = ok && vision_forward_device(ctx, (const float *)d_in, Bc, (float *)d_out, normalize);
-        ok = ok && hipMemcpyAsync(vec + (size_t)b0 * proj, d_out, (size_t)proj * 4 * Bc, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    }
+    // pinned, threaded, double-buffered staging (host_pipeline.cpp): pack(k+1) || H2D(k) || forward(k-1)
+    bool ok = encode_images_from_host(ctx, imgs->data, B, (float *)ctx->io_out, normalize, nt);
+    ok = ok && hipMemcpyAsync(vec, ctx->io_out, (size_t)proj * 4 * B, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    ok = hipStreamSynchronize(ctx->stream) == hipSuccess && ok;
     if (!ok) fprintf(stderr, "clip_image_batch_encode: HIP error: %s\n", hipGetErrorString(hipGetLastError()));
     if (ctx->profiling) prof_collect(ctx);
     return ok;
@@ -633,6 +656,21 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     if (hipEventSynchronize(b) == hipSuccess && hipGetLastError() == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    if (getenv("CLIPAMD_G8_STAMPS")) {   // tuning builds (-DCLIPAMD_G8_TIMING): dump the per-workgroup phase stamps of the last launch
+        const int nwg = 4096;
+        std::vector<unsigned long long> st((size_t)nwg * 8);
+        (void)hipMemcpy(st.data(), skw.p, st.size() * 8, hipMemcpyDeviceToHost);
+        FILE * f = fopen(getenv("CLIPAMD_G8_STAMPS"), "a");
+        if (f) {
+            fprintf(f, "# N=%lld K=%lld M=%lld epi=%d tile=%d\n", (long long)N, (long long)K, (long long)M, epilogue, tile);
+            for (int i = 0; i < nwg; i++) {
+                const unsigned long long * s8 = &st[(size_t)i * 8];
+                if (!s8[0] || !s8[3]) continue;
+                fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, s8[0], s8[1], s8[2], s8[3], s8[5], s8[4], s8[6]);
+            }
+            fclose(f);
+        }
+    }
     (void)hipFree(wbase);
     return ms < 0 ? -4.f : ms * 1000.f / iters;
 }

@@ -72,7 +72,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
         launch_gemm(p, epi, 0, ctx->stream);
         return;
     }
-    const int tile = gemm_tile_for(p.M, p.W.N);
+    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad);
     const bool panel = gemm_tile_uses_panel(tile) && (p.W.wtype == W_F16 || p.w16_pre);
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double wb = panel ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);   // the 8-wave kernel reads the fp16 panel of W
@@ -109,11 +109,11 @@ LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows) {
     int nj = 0;
     size_t need = 0;
     for (int i = 0; i < 4; i++)
-        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N))) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
+        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad))) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
     if (!need || !ensure_panel(ctx, need)) return lp;
     size_t off = 0;
     for (int i = 0; i < 4; i++)
-        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N))) {
+        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad))) {
             jw[nj] = ws[i];
             jo[nj] = ctx->w16_panel + off;
             *slot[i] = jo[nj];
@@ -418,12 +418,31 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     Carver c(ctx->ws.base);
     carve(c, x, xn, qkv, att, mid, pooled, emb, seq, last);
     {
-        std::vector<int> hs(2 * (size_t)n_texts + 1);
+        // sequence offsets + last-token rows (EOS, clip.cpp:1154-1155): written into a slot of a pinned ring and uploaded
+        // asynchronously — the host does not wait for the stream (a slot is re-used 8 calls later; only then, and only if its
+        // upload is somehow still pending, does the event wait block)
+        MetaRing & mr = ctx->meta;
+        const int sl = mr.next;
+        mr.next = (mr.next + 1) % MetaRing::SLOTS;
+        const size_t n_ints = 2 * (size_t)n_texts + 1;
+        if (!mr.ev[sl] && hipEventCreateWithFlags(&mr.ev[sl], hipEventDisableTiming) != hipSuccess) return false;
+        if (mr.busy[sl]) (void)hipEventSynchronize(mr.ev[sl]);
+        if (mr.cap[sl] < n_ints) {
+            if (mr.pin[sl]) (void)hipHostFree(mr.pin[sl]);
+            mr.pin[sl] = nullptr;
+            mr.cap[sl] = 0;
+            const size_t want = std::max<size_t>(n_ints, 1024);
+            if (hipHostMalloc((void **)&mr.pin[sl], want * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+            mr.cap[sl] = want;
+        }
+        int * hs = mr.pin[sl];
         for (int i = 0; i <= n_texts; i++) hs[i] = h_offsets[i] - h_offsets[0];
-        for (int i = 0; i < n_texts; i++) hs[n_texts + 1 + i] = hs[i + 1] - 1;   // last token row (EOS) — clip.cpp:1154-1155
-        (void)hipMemcpyAsync(seq, hs.data(), ((size_t)n_texts + 1) * 4, hipMemcpyHostToDevice, s);
-        (void)hipMemcpyAsync(last, hs.data() + n_texts + 1, (size_t)n_texts * 4, hipMemcpyHostToDevice, s);
-        (void)hipStreamSynchronize(s);
+        for (int i = 0; i < n_texts; i++) hs[n_texts + 1 + i] = hs[i + 1] - 1;
+        // seq and last are carved back to back but 256-byte aligned: two copies
+        (void)hipMemcpyAsync(seq, hs, ((size_t)n_texts + 1) * 4, hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(last, hs + n_texts + 1, (size_t)n_texts * 4, hipMemcpyHostToDevice, s);
+        (void)hipEventRecord(mr.ev[sl], s);
+        mr.busy[sl] = true;
     }
     auto launch_all = [&]() -> bool {
         launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)

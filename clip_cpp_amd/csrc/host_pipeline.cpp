@@ -1,0 +1,326 @@
+// host_pipeline.cpp — the host-pointer side of clip_image_batch_encode (reference clip.cpp:1247-1523, input pack :1285-1307,
+// result copy :1514) for the MI355X build, and its multi-GPU form.
+//
+// 1. encode_images_from_host: the caller's images are B separate pageable allocations of S*S*3 floats.  Copying them with one
+//    hipMemcpyAsync each lets the driver bounce every image through its own staging buffer on ONE thread (measured r01:
+//    20.6k img/s against 72k device-resident).  Here `n_threads` host threads pack sub-chunks of the batch into a pinned buffer;
+//    as soon as a sub-chunk is packed its single H2D copy is queued on a copy stream, and the vision tower runs on it on the
+//    compute stream as soon as that copy lands — pack(k+1) || H2D(k) || forward(k-1).  Two pinned / device buffer pairs
+//    alternate between chunks (<= 256 images), so packing of chunk c+1 overlaps the GPU work of chunk c.
+//
+// 2. clip_amd_model_load_multi / multi_image_batch_encode: single process, one replica context + stream + host thread per
+//    device, contiguous shards of ceil(B/G) images (only its shard is copied to a device), identical kernels, then ONE
+//    ncclAllGather (RCCL over xGMI) of the [B_g][proj] f32 rows into [G * B_g][proj] on every device and one D2H from
+//    device 0 into the caller's `vec`.  RCCL is bound with dlopen at load time, so single-GPU users of libclip.so do not need it.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <thread>
+#include <vector>
+
+#include "../../include/clip_amd.h"
+#include "model.h"
+
+namespace clipamd {
+
+namespace {
+
+bool grow_pinned(void *& p, size_t & have, size_t want) {
+    if (have >= want) return true;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    have = 0;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    have = want;
+    return true;
+}
+
+bool grow_device(void *& p, size_t & have, size_t want) {
+    if (have >= want) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    have = 0;
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+    have = want;
+    return true;
+}
+
+}  // namespace
+
+int host_pipeline_subchunk(int n) {
+    static int forced = -1;
+    if (forced < 0) { const char * e = getenv("CLIP_AMD_HOST_SUBCHUNK"); forced = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (forced) return forced;
+    return n <= 32 ? n : 64;
+}
+
+// n preprocessed images (host, S x S x 3 floats each, checked by the caller) -> d_out [n][proj] on ctx's device.
+// Returns with all host-side work done (the caller's buffers are no longer read) and the device work QUEUED on ctx->stream.
+bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n, float * d_out, bool normalize, int n_threads) {
+    if (n <= 0) return true;
+    const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
+    const size_t per = (size_t)S * S * 3, per_bytes = per * sizeof(float);
+    (void)hipSetDevice(ctx->device);
+    HostPipe & hp = ctx->pipe;
+    if (!hp.copy_stream) {
+        if (hipStreamCreateWithFlags(&hp.copy_stream, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < 2; i++)
+            if (hipEventCreateWithFlags(&hp.ev_copied[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&hp.ev_consumed[i], hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&hp.ev_sub, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    int chunk = (int)std::min<size_t>(256, std::max<size_t>(1, ((size_t)192 << 20) / per_bytes));
+    chunk = std::min(chunk, n);
+    const int n_chunks = (n + chunk - 1) / chunk;
+    const int nbuf = n_chunks > 1 ? 2 : 1;
+    for (int i = 0; i < nbuf; i++) {
+        if (hp.dev_in_bytes[i] < (size_t)chunk * per_bytes || hp.pin_in_bytes[i] < (size_t)chunk * per_bytes) {
+            (void)hipStreamSynchronize(ctx->stream);       // (re)allocation: nothing may still be using the old buffers
+            (void)hipStreamSynchronize(hp.copy_stream);
+            drop_graphs(ctx);                              // captured graphs hold the old device input pointer
+        }
+        if (!grow_pinned(hp.pin_in[i], hp.pin_in_bytes[i], (size_t)chunk * per_bytes) || !grow_device(hp.dev_in[i], hp.dev_in_bytes[i], (size_t)chunk * per_bytes)) {
+            fprintf(stderr, "clip_image_batch_encode: cannot allocate %zu MB of staging memory\n", ((size_t)chunk * per_bytes) >> 20);
+            return false;
+        }
+    }
+    const int P = std::max(1, std::min({n_threads, 16, n}));
+    bool ok = true;
+    for (int c = 0; c < n_chunks && ok; c++) {
+        const int b0 = c * chunk, bc = std::min(chunk, n - b0), buf = c & 1;
+        float * pin = (float *)hp.pin_in[buf];
+        float * dev = (float *)hp.dev_in[buf];
+        if (c >= 2) {
+            ok = ok && hipEventSynchronize(hp.ev_copied[buf]) == hipSuccess;                           // pinned buffer: H2Ds of chunk c-2 done
+            ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;        // device buffer: forwards of chunk c-2 done
+        } else if (hp.used[buf]) {
+            // first use in this call of a buffer an earlier call may still be reading (device side only: calls end synchronised
+            // on the host side, so the pinned buffer is free)
+            ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;
+        }
+        hp.used[buf] = true;
+        const int sc = host_pipeline_subchunk(bc);
+        const int n_sub = (bc + sc - 1) / sc;
+        std::vector<std::atomic<int>> packed(n_sub);
+        for (auto & a : packed) a.store(0, std::memory_order_relaxed);
+        auto pack = [&](int t) {
+            for (int i = t; i < bc; i += P) {                 // image i of the chunk; sub-chunks fill in order
+                memcpy(pin + per * i, imgs[b0 + i].data, per_bytes);
+                packed[i / sc].fetch_add(1, std::memory_order_release);
+            }
+        };
+        std::vector<std::thread> pool;
+        if (P > 1 && bc >= 8) for (int t = 1; t < P; t++) pool.emplace_back(pack, t);
+        else { for (int t = 1; t < P; t++) pack(t); }
+        pack(0);
+        for (int k = 0; k < n_sub && ok; k++) {
+            const int s0 = k * sc, sn = std::min(sc, bc - s0);
+            while (packed[k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
+            ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
+            ok = ok && hipEventRecord(hp.ev_sub, hp.copy_stream) == hipSuccess;
+            ok = ok && hipStreamWaitEvent(ctx->stream, hp.ev_sub, 0) == hipSuccess;
+            ok = ok && vision_forward_device(ctx, dev + per * s0, sn, d_out + (size_t)(b0 + s0) * proj, normalize);
+        }
+        for (auto & th : pool) th.join();
+        ok = ok && hipEventRecord(hp.ev_copied[buf], hp.copy_stream) == hipSuccess;
+        ok = ok && hipEventRecord(hp.ev_consumed[buf], ctx->stream) == hipSuccess;
+    }
+    return ok;
+}
+
+void free_host_pipe(clip_ctx * ctx) {
+    HostPipe & hp = ctx->pipe;
+    for (int i = 0; i < 2; i++) {
+        if (hp.pin_in[i]) (void)hipHostFree(hp.pin_in[i]);
+        if (hp.dev_in[i]) (void)hipFree(hp.dev_in[i]);
+        if (hp.ev_copied[i]) (void)hipEventDestroy(hp.ev_copied[i]);
+        if (hp.ev_consumed[i]) (void)hipEventDestroy(hp.ev_consumed[i]);
+    }
+    if (hp.ev_sub) (void)hipEventDestroy(hp.ev_sub);
+    if (hp.copy_stream) (void)hipStreamDestroy(hp.copy_stream);
+    hp = HostPipe();
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU
+// ---------------------------------------------------------------------------------------------
+void multi_shard(int total, int n_dev, int g, int * lo, int * hi, int * per_dev) {
+    const int bs = (total + n_dev - 1) / n_dev;          // contiguous shards of ceil(B / G); trailing shards may be short or empty
+    *per_dev = bs;
+    *lo = std::min(total, g * bs);
+    *hi = std::min(total, (g + 1) * bs);
+}
+
+namespace {
+
+typedef void * ncclComm_t;
+struct Rccl {
+    void * handle = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char * (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (handle) return true;
+        const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char * nm : names) {
+            handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) { fprintf(stderr, "clip_amd_model_load_multi: cannot load RCCL (%s)\n", dlerror()); return false; }
+        CommInitAll = (int (*)(ncclComm_t *, int, const int *))dlsym(handle, "ncclCommInitAll");
+        CommDestroy = (int (*)(ncclComm_t))dlsym(handle, "ncclCommDestroy");
+        AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t, hipStream_t))dlsym(handle, "ncclAllGather");
+        GroupStart = (int (*)())dlsym(handle, "ncclGroupStart");
+        GroupEnd = (int (*)())dlsym(handle, "ncclGroupEnd");
+        GetErrorString = (const char * (*)(int))dlsym(handle, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd) {
+            fprintf(stderr, "clip_amd_model_load_multi: RCCL library lacks a required symbol\n");
+            return false;
+        }
+        return true;
+    }
+};
+constexpr int kNcclFloat = 7;   // ncclFloat32 (rccl.h ncclDataType_t)
+
+}  // namespace
+
+struct MultiCtx {
+    int G = 0;
+    std::vector<clip_ctx *> rep;          // rep[0] is the primary (the handle the caller holds)
+    std::vector<ncclComm_t> comms;
+    std::vector<float *> send, recv;      // per device: [per_dev][proj] and [G * per_dev][proj]
+    std::vector<size_t> send_floats, recv_floats;
+    Rccl rccl;
+    bool use_rccl = true;
+};
+
+clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+    if (n_devices <= 0) n_devices = ndev;
+    if (ndev <= 0 || n_devices > ndev) {
+        fprintf(stderr, "clip_amd_model_load_multi: %d devices requested, %d visible\n", n_devices, ndev);
+        return nullptr;
+    }
+    MultiCtx * mc = new MultiCtx();
+    mc->G = n_devices;
+    for (int g = 0; g < n_devices; g++) {
+        clip_ctx * c = load_model(fname, g == 0 ? verbosity : 0, g);
+        if (!c) {
+            for (clip_ctx * r : mc->rep) free_model(r);
+            delete mc;
+            return nullptr;
+        }
+        mc->rep.push_back(c);
+    }
+    mc->send.assign(n_devices, nullptr); mc->recv.assign(n_devices, nullptr);
+    mc->send_floats.assign(n_devices, 0); mc->recv_floats.assign(n_devices, 0);
+    if (n_devices > 1) {
+        const char * e = getenv("CLIP_AMD_MULTI_NO_RCCL");   // debugging aid: G device-to-host copies into disjoint slices instead of the all-gather
+        mc->use_rccl = !(e && e[0] == '1');
+        if (mc->use_rccl) {
+            std::vector<int> devs(n_devices);
+            for (int g = 0; g < n_devices; g++) devs[g] = g;
+            mc->comms.assign(n_devices, nullptr);
+            int rc = -1;
+            if (!mc->rccl.load() || (rc = mc->rccl.CommInitAll(mc->comms.data(), n_devices, devs.data())) != 0) {
+                fprintf(stderr, "clip_amd_model_load_multi: ncclCommInitAll failed (%s)\n", rc > 0 && mc->rccl.GetErrorString ? mc->rccl.GetErrorString(rc) : "RCCL unavailable");
+                for (clip_ctx * r : mc->rep) free_model(r);
+                delete mc;
+                return nullptr;
+            }
+        }
+    }
+    mc->rep[0]->multi = mc;
+    (void)hipSetDevice(0);
+    return mc->rep[0];
+}
+
+void multi_free(clip_ctx * primary) {
+    MultiCtx * mc = (MultiCtx *)primary->multi;
+    if (!mc) return;
+    primary->multi = nullptr;
+    for (int g = 0; g < mc->G; g++) {
+        (void)hipSetDevice(mc->rep[g]->device);
+        if (mc->send[g]) (void)hipFree(mc->send[g]);
+        if (mc->recv[g]) (void)hipFree(mc->recv[g]);
+        if (g < (int)mc->comms.size() && mc->comms[g]) mc->rccl.CommDestroy(mc->comms[g]);
+    }
+    for (int g = 1; g < mc->G; g++) free_model(mc->rep[g]);
+    delete mc;
+}
+
+int multi_device_count(const clip_ctx * primary) { return primary && primary->multi ? ((MultiCtx *)primary->multi)->G : 1; }
+
+// B images sharded over the G devices of a multi context; vec [B][proj] on the host.
+bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, int B, float * vec, bool normalize, int n_threads) {
+    MultiCtx * mc = (MultiCtx *)primary->multi;
+    const int G = mc->G, proj = primary->vision_hparams.projection_dim;
+    int per_dev = 0, lo = 0, hi = 0;
+    multi_shard(B, G, 0, &lo, &hi, &per_dev);
+    std::vector<char> okv(G, 1);
+    const int thr = std::max(1, n_threads / G);
+    auto work = [&](int g) {
+        clip_ctx * c = mc->rep[g];
+        (void)hipSetDevice(c->device);
+        void * sp = mc->send[g], * rp = mc->recv[g];
+        size_t sb = mc->send_floats[g] * 4, rb = mc->recv_floats[g] * 4;
+        const bool grew = sb < (size_t)per_dev * proj * 4 || rb < (size_t)G * per_dev * proj * 4;
+        if (grew) (void)hipStreamSynchronize(c->stream);
+        if (!grow_device(sp, sb, (size_t)per_dev * proj * 4) || !grow_device(rp, rb, (size_t)G * per_dev * proj * 4)) { okv[g] = 0; return; }
+        mc->send[g] = (float *)sp; mc->recv[g] = (float *)rp; mc->send_floats[g] = sb / 4; mc->recv_floats[g] = rb / 4;
+        int l, h, pd;
+        multi_shard(B, G, g, &l, &h, &pd);
+        if (h - l < per_dev) (void)hipMemsetAsync(mc->send[g] + (size_t)(h - l) * proj, 0, (size_t)(per_dev - (h - l)) * proj * 4, c->stream);   // padding rows of a short shard
+        if (h > l && !encode_images_from_host(c, imgs + l, h - l, mc->send[g], normalize, thr)) okv[g] = 0;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int g = 1; g < G; g++) pool.emplace_back(work, g);
+        work(0);
+        for (auto & th : pool) th.join();
+    }
+    for (int g = 0; g < G; g++) if (!okv[g]) { fprintf(stderr, "clip_image_batch_encode: shard %d failed\n", g); return false; }
+    bool ok = true;
+    if (G > 1 && mc->use_rccl) {
+        // ONE all-gather of the final embeddings: [per_dev][proj] per device -> [G * per_dev][proj] on every device
+        ok = mc->rccl.GroupStart() == 0;
+        for (int g = 0; g < G && ok; g++)
+            ok = mc->rccl.AllGather(mc->send[g], mc->recv[g], (size_t)per_dev * proj, kNcclFloat, mc->comms[g], mc->rep[g]->stream) == 0;
+        ok = (mc->rccl.GroupEnd() == 0) && ok;
+        if (!ok) { fprintf(stderr, "clip_image_batch_encode: ncclAllGather failed\n"); return false; }
+        (void)hipSetDevice(primary->device);
+        // shards are contiguous and only the LAST non-empty one can be short, so the first B rows of the gathered buffer are the result
+        ok = hipMemcpyAsync(vec, mc->recv[0], (size_t)B * proj * 4, hipMemcpyDeviceToHost, primary->stream) == hipSuccess;
+        for (int g = 0; g < G; g++) {
+            (void)hipSetDevice(mc->rep[g]->device);
+            ok = hipStreamSynchronize(mc->rep[g]->stream) == hipSuccess && ok;
+        }
+    } else {
+        for (int g = 0; g < G; g++) {
+            int l, h, pd;
+            multi_shard(B, G, g, &l, &h, &pd);
+            (void)hipSetDevice(mc->rep[g]->device);
+            if (h > l) ok = hipMemcpyAsync(vec + (size_t)l * proj, mc->send[g], (size_t)(h - l) * proj * 4, hipMemcpyDeviceToHost, mc->rep[g]->stream) == hipSuccess && ok;
+        }
+        for (int g = 0; g < G; g++) {
+            (void)hipSetDevice(mc->rep[g]->device);
+            ok = hipStreamSynchronize(mc->rep[g]->stream) == hipSuccess && ok;
+        }
+    }
+    (void)hipSetDevice(primary->device);
+    return ok;
+}
+
+// device-resident gathered result of the last multi encode on device g (tests / callers that keep the embeddings on the GPUs)
+const float * multi_gathered(const clip_ctx * primary, int g) {
+    const MultiCtx * mc = (const MultiCtx *)primary->multi;
+    return mc && g >= 0 && g < mc->G ? mc->recv[g] : nullptr;
+}
+
+}  // namespace clipamd

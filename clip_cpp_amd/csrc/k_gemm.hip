@@ -390,16 +390,18 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
 // one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
-int pick_tile(int M, int N) {
+int pick_tile(int M, int N, int Kpad) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
     if (wgs(128, 128) < 100) return wgs(64, 128) >= 256 ? 64128 : 64064;
-    // large M: the 8-wave 160 x 256 kernel (k_gemm8.hip), one workgroup per CU -> rounds of 256 tiles
+    // large M: the 8-wave 160 x 256 kernel (k_gemm8.hip), one workgroup per CU -> rounds of 256 tiles.  Its K loop is the faster
+    // one (3-stage ring, ping-pong: ~69 % of the MFMA peak in the loop) but with one workgroup per CU nothing overlaps a tile's
+    // prologue and epilogue, so it wins where the K loop dominates the tile: long K, or many rounds (profiles/r02_gemm8_*.txt)
     {
         const int t8 = wgs(160, 256);
         const float rounds = (float)t8 / 256.f;
         const float eff = rounds / ceilf(rounds);          // fraction of the last round's CUs that have work
-        if (t8 >= 200 && eff >= 0.75f) return 160256;
+        if (t8 >= 200 && eff >= 0.75f && (Kpad >= 2048 || M >= 32768)) return 160256;
     }
     int best = 128128;
     float best_cost = 0.f;
@@ -431,7 +433,7 @@ void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
-int gemm_tile_for(int M, int N) { return pick_tile(M, N); }
+int gemm_tile_for(int M, int N, int Kpad) { return pick_tile(M, N, Kpad); }
 
 // Split-K factor for a BM = 64 tile grid (small-M problems: batch 1 / 32, single texts), fitted with
 // scripts/gemm_bench.py (profiles/r01_gemm_splitk.txt): a K-step costs ~0.5 us of serial latency, the fix-up ~3 us, so
@@ -451,7 +453,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
     const bool heuristic = (tile == 0);
     int ksplit = tile / 1000000;        // explicit: ksplit * 1000000 + BM * 1000 + BN  (no prefix = no split)
     tile %= 1000000;
-    if (heuristic) tile = pick_tile(p.M, p.W.N);
+    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad);
     if (gemm_tile_uses_panel(tile)) {
         // 8-wave large-M kernel: fp16 x fp16 from a row-major panel of W; block-quantised weights are dequantised into it first
         // (unless the caller already did, per layer)

@@ -32,6 +32,10 @@
 
 #include "gemm_common.h"
 
+#ifndef CLIPAMD_G8_PHASES
+#define CLIPAMD_G8_PHASES 2   // MFMA segments per K-tile: 2 = one per 32-wide k-slice, 1 = one per K-tile (tuning: scripts/build_variant.sh)
+#endif
+
 namespace clipamd {
 
 namespace {
@@ -130,8 +134,20 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
 
     // one k-slice: [load segment: fragment reads (+ the caller's DMA / wait work), retired before the barrier] barrier
     //              [MFMA segment at raised priority] barrier
+#ifdef CLIPAMD_ABLATION   // tuning builds (scripts/build_variant.sh NAME -DCLIPAMD_ABLATION): p.debug bit 0 no DMA in the loop, bit 1 no MFMA, bit 2 no fragment reads
+    const bool ab_nodma = p.debug & 1, ab_nomfma = p.debug & 2, ab_noread = p.debug & 4;
+#define AB_DMA(x_) if (!ab_nodma) x_
+#define AB_READ if (!ab_noread)
+#define AB_MFMA if (!ab_nomfma)
+#define AB_INIT _Pragma("unroll") for (int a = 0; a < TN; a++) wf[a] = (h8)(_Float16)1.0f; _Pragma("unroll") for (int b = 0; b < TM; b++) xf[b] = (h8)(_Float16)1.0f;
+#else
+#define AB_INIT
+#define AB_DMA(x_) x_
+#define AB_READ
+#define AB_MFMA
+#endif
 #define READ_FRAGS(st_, kk_)                                                                                      \
-    {                                                                                                             \
+    AB_READ {                                                                                                     \
         const unsigned char * sb = smem + (st_) * STAGE;                                                          \
         const int so = (kk_) ? (sw ^ 64) : sw;                                                                    \
         _Pragma("unroll") for (int a = 0; a < TN; a++) wf[a] = *(const h8 *)(sb + lw + a * 2048 + so);            \
@@ -142,30 +158,67 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
         wait_lgkm0();                                                                                             \
         raw_barrier();                                                                                            \
         __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int a = 0; a < TN; a++)                                                            \
+        AB_MFMA _Pragma("unroll") for (int a = 0; a < TN; a++)                                                    \
             _Pragma("unroll") for (int b = 0; b < TM; b++)                                                        \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);             \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         raw_barrier();                                                                                            \
     }
     // K-tile t lives in stage ST; its segments request tile t + 2 into stage (ST + 2) % 3 (the stage of tile t - 1)
+#if CLIPAMD_G8_PHASES == 1
+    // one load segment + one 2 x TN x TM MFMA segment per K-tile: half the barriers, twice the cover per segment
+#define KTILE(ST, t_)                                                                                             \
+    {                                                                                                             \
+        h8 wf[TN], xf[TM], wf1[TN], xf1[TM];                                                                      \
+        AB_INIT                                                                                                   \
+        const bool more = (t_) + 2 < T;                                                                           \
+        if (more) {                                                                                               \
+            AB_DMA(ISSUE_W((ST + 2) % 3, (t_) + 2));                                                              \
+            AB_DMA(ISSUE_X((ST + 2) % 3, (t_) + 2));                                                              \
+        }                                                                                                         \
+        READ_FRAGS(ST, 0);                                                                                        \
+        AB_READ {                                                                                                 \
+            const unsigned char * sb = smem + (ST) * STAGE;                                                       \
+            _Pragma("unroll") for (int a = 0; a < TN; a++) wf1[a] = *(const h8 *)(sb + lw + a * 2048 + (sw ^ 64)); \
+            _Pragma("unroll") for (int b = 0; b < TM; b++) xf1[b] = *(const h8 *)(sb + lx + b * 2048 + (sw ^ 64)); \
+        }                                                                                                         \
+        if (more) wait_vmcnt<NW + NX>(); else wait_vmcnt<0>();   /* tile t + 1 has landed (this wave's part) */   \
+        wait_lgkm0();                                                                                             \
+        raw_barrier();                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        AB_MFMA {                                                                                                 \
+            _Pragma("unroll") for (int a = 0; a < TN; a++)                                                        \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                                    \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);         \
+            _Pragma("unroll") for (int a = 0; a < TN; a++)                                                        \
+                _Pragma("unroll") for (int b = 0; b < TM; b++)                                                    \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[a], xf1[b], acc[a][b], 0, 0, 0);       \
+        }                                                                                                         \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+        raw_barrier();                                                                                            \
+    }
+#else
 #define KTILE(ST, t_)                                                                                             \
     {                                                                                                             \
         h8 wf[TN], xf[TM];                                                                                        \
+        AB_INIT                                                                                                   \
         const bool more = (t_) + 2 < T;                                                                           \
+        if (more) AB_DMA(ISSUE_W((ST + 2) % 3, (t_) + 2));                                                        \
         READ_FRAGS(ST, 0);                                                                                        \
-        if (more) ISSUE_W((ST + 2) % 3, (t_) + 2);                                                                \
         MFMA_SEGMENT();                                                                                           \
+        if (more) wait_vmcnt<NW>();   /* all but the NW requests just made: tile t + 1 has landed (this wave's part) */ \
+        else wait_vmcnt<0>();                                                                                     \
+        if (more) AB_DMA(ISSUE_X((ST + 2) % 3, (t_) + 2));                                                        \
         READ_FRAGS(ST, 1);                                                                                        \
-        if (more) {                                                                                               \
-            wait_vmcnt<NW>();      /* all but the NW requests just made: tile t + 1 has landed (this wave's part) */ \
-            ISSUE_X((ST + 2) % 3, (t_) + 2);                                                                      \
-        } else {                                                                                                  \
-            wait_vmcnt<0>();                                                                                      \
-        }                                                                                                         \
         MFMA_SEGMENT();                                                                                           \
     }
+#endif
 
+#ifdef CLIPAMD_G8_TIMING   // tuning builds: per-workgroup phase stamps (shader clock) into the split-K workspace: start, loop, epilogue, end
+    unsigned long long * stamp = (unsigned long long *)p.sk_ws + (size_t)blockIdx.x * 8;
+    const bool stamper = p.sk_ws && tid == 0;
+    if (stamper) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     ISSUE_W(0, 0);
     ISSUE_X(0, 0);
     if (T > 1) {
@@ -176,6 +229,9 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
         wait_vmcnt<0>();
     }
     raw_barrier();
+#ifdef CLIPAMD_G8_TIMING
+    if (stamper) stamp[1] = __builtin_amdgcn_s_memtime();
+#endif
     if (wm == 1) raw_barrier();                        // stagger: group 1 runs one segment behind group 0
     for (int t = 0; t < T; t += 3) {
         KTILE(0, t);
@@ -190,13 +246,25 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
 #undef ISSUE_W
 
     const int nb = n0 + wn * 64, mb = m0 + wm * TM * 16;
+#ifdef CLIPAMD_G8_TIMING
+    if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();
+#endif
+    bool done = false;
     if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
         if (nb + 64 <= p.W.N && (p.ldc & 7) == 0) {    // uniform per wave
             gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, (half_t *)smem + wave * (TM * 16) * 68, lane);
-            return;
+            done = true;
         }
     }
-    gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp);
+    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp);
+#ifdef CLIPAMD_G8_TIMING
+    if (stamper) {
+        stamp[3] = __builtin_amdgcn_s_memtime();       // stores issued (not necessarily landed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[5] = __builtin_amdgcn_s_memtime();       // this wave's stores acknowledged
+        stamp[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <int TM, int EPI>

@@ -402,9 +402,17 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
 
 void free_model(clip_ctx * ctx) {
     if (!ctx) return;
+    if (ctx->multi) multi_free(ctx);     // replicas on the other devices, RCCL communicators
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+        if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+        free_host_pipe(ctx);
+        for (int i = 0; i < MetaRing::SLOTS; i++) {
+            if (ctx->meta.pin[i]) (void)hipHostFree(ctx->meta.pin[i]);
+            if (ctx->meta.ev[i]) (void)hipEventDestroy(ctx->meta.ev[i]);
+        }
+        if (ctx->ev_stream_switch) (void)hipEventDestroy(ctx->ev_stream_switch);
         for (auto & p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         drop_graphs(ctx);
         if (ctx->ws.base) (void)hipFree(ctx->ws.base);

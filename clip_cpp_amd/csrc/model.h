@@ -50,6 +50,31 @@ struct Workspace {
     size_t bytes = 0;
 };
 
+// Host -> device staging of the host-pointer API (host_pipeline.cpp): two pinned / device buffer pairs that alternate between
+// chunks of a batch, a copy stream, and the events that order pack -> H2D -> forward.
+struct HostPipe {
+    hipStream_t copy_stream = nullptr;
+    void * pin_in[2] = {nullptr, nullptr};
+    size_t pin_in_bytes[2] = {0, 0};
+    void * dev_in[2] = {nullptr, nullptr};
+    size_t dev_in_bytes[2] = {0, 0};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};     // last H2D out of pin_in[i]
+    hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // last forward reading dev_in[i]
+    hipEvent_t ev_sub = nullptr;
+    bool used[2] = {false, false};
+};
+
+// Pinned ring for the small per-call metadata of the text tower (sequence offsets): the upload is asynchronous and the
+// host never blocks on the stream (text_forward_device synchronised on every call).
+struct MetaRing {
+    static constexpr int SLOTS = 8;
+    int * pin[SLOTS] = {nullptr};
+    size_t cap[SLOTS] = {0};
+    hipEvent_t ev[SLOTS] = {nullptr};
+    bool busy[SLOTS] = {false};
+    int next = 0;
+};
+
 }  // namespace clipamd
 
 // The opaque handle of the C API (reference clip.h:8).
@@ -82,6 +107,10 @@ struct clip_ctx {
     size_t io_in_bytes = 0;
     void * io_out = nullptr;
     size_t io_out_bytes = 0;
+    clipamd::HostPipe pipe;          // pinned double-buffered staging of clip_image_batch_encode (host_pipeline.cpp)
+    clipamd::MetaRing meta;          // pinned ring for the text tower's per-call offsets
+    void * multi = nullptr;          // clipamd::MultiCtx* when loaded with clip_amd_model_load_multi (replicas on the other devices)
+    hipEvent_t ev_stream_switch = nullptr;   // orders a new stream behind the work queued on the previous one (clip_amd_set_stream)
     void * pre_buf = nullptr;        // device blob of the GPU preprocessing path (descriptors, taps, raw pixels, row buffer)
     size_t pre_bytes = 0;
     // split-K workspace of the GEMM (kernels.h GemmParams::sk_*): partial tiles + per-tile ticket counters (kept zero)
@@ -129,6 +158,16 @@ bool ensure_pinned(clip_ctx * ctx, size_t bytes);
 bool ensure_io(clip_ctx * ctx, size_t in_bytes, size_t out_bytes);
 void prof_collect(clip_ctx * ctx);
 void drop_graphs(clip_ctx * ctx);
+
+// host_pipeline.cpp — pinned, threaded host -> device staging + the multi-GPU form of clip_image_batch_encode
+bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n, float * d_out, bool normalize, int n_threads);
+void free_host_pipe(clip_ctx * ctx);
+void multi_shard(int total, int n_dev, int g, int * lo, int * hi, int * per_dev);
+clip_ctx * multi_load(const char * fname, int verbosity, int n_devices);
+void multi_free(clip_ctx * primary);
+int multi_device_count(const clip_ctx * primary);
+bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, int B, float * vec, bool normalize, int n_threads);
+const float * multi_gathered(const clip_ctx * primary, int g);
 
 // host pieces
 bool tokenize_text(const clip_ctx * ctx, const char * text, std::vector<int32_t> & out);            // tokenizer.cpp

@@ -21,11 +21,32 @@ int clip_amd_device_count(void);
  * clip_model_load uses $CLIP_AMD_DEVICE, else $LOCAL_RANK, else device 0. */
 struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int device);
 
+/* Multi-GPU form of clip_model_load (the reference has no multi-device path): ONE process, the weights
+ * replicated on the first n_devices HIP devices (n_devices <= 0: all visible), one context + stream + host thread per
+ * device behind the returned handle.  clip_image_batch_encode (reference clip.cpp:1247) on such a handle shards a batch
+ * of B >= 2 * n_devices images into contiguous runs of ceil(B / n_devices), copies to each device only its shard,
+ * runs the identical kernels, and collects the final embeddings with ONE ncclAllGather (RCCL over xGMI) of
+ * [ceil(B / n_devices)][projection_dim] f32 rows per device into [n_devices * ceil(B / n_devices)][projection_dim] on
+ * every device, then one device-to-host copy from device 0 into `vec`.  Everything else (text encode, small batches)
+ * runs on device 0.  RCCL (librccl.so) is bound with dlopen by this call only.  NULL on failure.  clip_free() releases
+ * every replica. */
+struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, int n_devices);
+/* Number of devices behind a handle (1 for clip_model_load / clip_amd_model_load handles). */
+int clip_amd_ctx_device_count(const struct clip_ctx * ctx);
+/* The shard clip_image_batch_encode gives device `device_index` of `n_devices` for a batch of `total` images: rows
+ * [*lo, *hi), and the padded per-device row count of the all-gather (pure arithmetic, no device needed). */
+void clip_amd_shard_bounds(int total, int n_devices, int device_index, int * lo, int * hi, int * rows_per_device);
+/* Device address (on device `device_index`) of the gathered [n_devices * rows_per_device][projection_dim] embeddings of
+ * the last sharded clip_image_batch_encode: the canonical device-resident result (valid until the next call). */
+const float * clip_amd_gathered_embeddings(const struct clip_ctx * ctx, int device_index);
+
 /* Which device a ctx lives on (-1: host-only ctx, see CLIP_AMD_ALLOW_NO_DEVICE in DESIGN.md). */
 int clip_amd_ctx_device(const struct clip_ctx * ctx);
 
 /* Bind all subsequent launches of this ctx to an existing HIP stream (e.g. torch's current
- * stream, as an integer handle).  NULL restores the ctx's own stream. */
+ * stream, as an integer handle).  NULL restores the ctx's own stream.  A context is single-stream and
+ * single-thread at any one time (it owns one activation workspace): the switch orders the new stream behind
+ * everything still queued on the previous one. */
 void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream);
 
 /* Device-resident form of clip_image_batch_encode (reference clip.cpp:1247-1523):
