@@ -270,7 +270,7 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
 
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
-    if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 64 || !ctx->has_vision_encoder)
+    if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder)
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);   // big batches are GPU-bound: no graph needed
     clip_ctx::GraphEntry * e = nullptr;
     for (auto & g : ctx->vgraphs)

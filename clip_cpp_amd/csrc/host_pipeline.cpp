@@ -13,6 +13,7 @@
 //    ncclAllGather (RCCL over xGMI) of the [B_g][proj] f32 rows into [G * B_g][proj] on every device and one D2H from
 //    device 0 into the caller's `vec`.  RCCL is bound with dlopen at load time, so single-GPU users of libclip.so do not need it.
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,7 +54,9 @@ int host_pipeline_subchunk(int n) {
     static int forced = -1;
     if (forced < 0) { const char * e = getenv("CLIP_AMD_HOST_SUBCHUNK"); forced = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (forced) return forced;
-    return n <= 32 ? n : 64;
+    // measured (profiles/r02_host_api.txt, ViT-B/32, 256 images per call): sub-chunks of 128 -> 34k img/s, 64 -> 30k, 256 (no overlap)
+    // -> 28k: the forward pass of a 64-image sub-chunk runs at half the per-image rate of a 256-image one, so finer overlap loses
+    return n < 192 ? n : 128;
 }
 
 // n preprocessed images (host, S x S x 3 floats each, checked by the caller) -> d_out [n][proj] on ctx's device.
@@ -88,6 +91,9 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
     }
     const int P = std::max(1, std::min({n_threads, 16, n}));
     bool ok = true;
+    static const bool timing = getenv("CLIP_AMD_HOST_TIMING") != nullptr;     // stderr: where a call's host time goes
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_wait_pack = 0, t_enqueue = 0;
     for (int c = 0; c < n_chunks && ok; c++) {
         const int b0 = c * chunk, bc = std::min(chunk, n - b0), buf = c & 1;
         float * pin = (float *)hp.pin_in[buf];
@@ -117,16 +123,23 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
         pack(0);
         for (int k = 0; k < n_sub && ok; k++) {
             const int s0 = k * sc, sn = std::min(sc, bc - s0);
+            const auto tw0 = std::chrono::steady_clock::now();
             while (packed[k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
+            const auto tw1 = std::chrono::steady_clock::now();
+            t_wait_pack += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
             ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
             ok = ok && hipEventRecord(hp.ev_sub, hp.copy_stream) == hipSuccess;
             ok = ok && hipStreamWaitEvent(ctx->stream, hp.ev_sub, 0) == hipSuccess;
             ok = ok && vision_forward_device(ctx, dev + per * s0, sn, d_out + (size_t)(b0 + s0) * proj, normalize);
+            t_enqueue += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
         }
         for (auto & th : pool) th.join();
         ok = ok && hipEventRecord(hp.ev_copied[buf], hp.copy_stream) == hipSuccess;
         ok = ok && hipEventRecord(hp.ev_consumed[buf], ctx->stream) == hipSuccess;
     }
+    if (timing)
+        fprintf(stderr, "encode_images_from_host: n=%d threads=%d chunk=%d | host %.2f ms (waiting for packers %.2f, enqueue H2D + forward %.2f)\n", n, P, chunk,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), t_wait_pack, t_enqueue);
     return ok;
 }
 

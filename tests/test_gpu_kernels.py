@@ -230,15 +230,18 @@ def test_gemm_text_tower_shapes_vs_dequant_reference(L, tname, shape):
     Xh = _h(X).astype(np.float64)
     want = Xh @ Wd.T + bias
     bound = 1.0e-3 * (np.abs(Xh) @ np.abs(Wd).T) + 1e-5
+    base = None
     for tile in (0, 192128, 128128, 160256):               # heuristic choice, the 192-row tile, a square tile, the 8-wave large-M kernel
         y = run_gemm(L, tid, raw, N, K, X, bias=bias, epi=0, tile=tile)
         assert np.all(np.isfinite(y))
         bad = np.argwhere(np.abs(y - want) > bound)
         assert bad.size == 0, "tile %d: %d/%d bad, first %s got %g want %g" % (tile, len(bad), y.size, bad[0], y[tuple(bad[0])], want[tuple(bad[0])])
         if tile == 0:
+            continue                                       # the heuristic may split K at small M: fp32 re-association, bound only
+        if base is None:
             base = y
         else:
-            assert np.array_equal(y, base), "tile %d differs bitwise from the heuristic tile" % tile
+            assert np.array_equal(y, base), "tile %d differs bitwise from tile 192128" % tile
     # the residual epilogue (out-proj / FFN-down, f32 stream) at the same shape
     resid = rng.standard_normal((M, N)).astype(np.float32)
     yr = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=4)
