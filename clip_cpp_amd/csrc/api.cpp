@@ -1,12 +1,14 @@
 // api.cpp — the extern "C" boundary: every symbol of include/clip.h (= reference clip.h:42-109) plus
 // the MI355X extensions of include/clip_amd.h.  Thin shim: argument checking, host<->HBM staging,
-// then forward.cpp.  Nothing here throws across the ABI.
+// then forward.cpp.  Nothing here throws across the ABI: every entry point that parses a file or allocates in
+// proportion to caller input is a function-try-block that turns an exception (bad_alloc, length_error, ...) into NULL / false.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -49,14 +51,14 @@ int64_t ggml_time_us(void) {
 int64_t ggml_time_ms(void) { return ggml_time_us() / 1000; }
 
 // ---- model lifetime ----
-struct clip_ctx * clip_model_load(const char * fname, const int verbosity) {
+struct clip_ctx * clip_model_load(const char * fname, const int verbosity) try {
     if (!fname) return nullptr;
     return load_model(fname, verbosity, default_device());
-}
-struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int device) {
+} catch (const std::exception & e) { fprintf(stderr, "clip_model_load: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_model_load: unknown exception\n"); return nullptr; }
+struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int device) try {
     if (!fname) return nullptr;
     return load_model(fname, verbosity, device);
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_amd_model_load: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_amd_model_load: unknown exception\n"); return nullptr; }
 void clip_free(struct clip_ctx * ctx) { free_model(ctx); }
 struct clip_text_hparams * clip_get_text_hparams(struct clip_ctx * ctx) { return &ctx->text_hparams; }
 struct clip_vision_hparams * clip_get_vision_hparams(struct clip_ctx * ctx) { return &ctx->vision_hparams; }
@@ -83,10 +85,10 @@ void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream) {
     }
     ctx->stream = next;
 }
-struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, int n_devices) {
+struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, int n_devices) try {
     if (!fname) return nullptr;
     return multi_load(fname, verbosity, n_devices);
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_amd_model_load_multi: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_amd_model_load_multi: unknown exception\n"); return nullptr; }
 int clip_amd_ctx_device_count(const struct clip_ctx * ctx) { return ctx ? multi_device_count(ctx) : 0; }
 void clip_amd_shard_bounds(int total, int n_devices, int device_index, int * lo, int * hi, int * rows_per_device) {
     int l = 0, h = 0, p = 0;
@@ -101,7 +103,7 @@ void clip_amd_synchronize(struct clip_ctx * ctx) {
 }
 
 // ---- tokenizer ----
-bool clip_tokenize(const struct clip_ctx * ctx, const char * text, struct clip_tokens * tokens) {
+bool clip_tokenize(const struct clip_ctx * ctx, const char * text, struct clip_tokens * tokens) try {
     if (!ctx->has_text_encoder) {
         printf("This GGUF file seems to have no text encoder\n");
         return false;
@@ -112,7 +114,7 @@ bool clip_tokenize(const struct clip_ctx * ctx, const char * text, struct clip_t
     tokens->data = new clip_vocab_id[v.size()];   // caller-owned, as in the reference (clip.cpp:675)
     std::copy(v.begin(), v.end(), tokens->data);
     return true;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_tokenize: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_tokenize: unknown exception\n"); return false; }
 
 // ---- image containers ----
 struct clip_image_u8 * clip_image_u8_make() { return new clip_image_u8(); }
@@ -126,7 +128,7 @@ void clip_image_f32_clean(struct clip_image_f32 * res) {
 void clip_image_u8_free(struct clip_image_u8 * img) { if (img) { clip_image_u8_clean(img); delete img; } }
 void clip_image_f32_free(struct clip_image_f32 * res) { if (res) { clip_image_f32_clean(res); delete res; } }
 
-bool clip_image_load_from_file(const char * fname, struct clip_image_u8 * img) { return load_image_file(fname, img); }
+bool clip_image_load_from_file(const char * fname, struct clip_image_u8 * img) try { return load_image_file(fname, img); } catch (const std::exception & e) { fprintf(stderr, "clip_image_load_from_file: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_image_load_from_file: unknown exception\n"); return false; }
 bool clip_image_preprocess(const struct clip_ctx * ctx, const struct clip_image_u8 * img, struct clip_image_f32 * res) {
     return preprocess_image(ctx, img, res);
 }
@@ -149,7 +151,7 @@ void clip_image_batch_preprocess(const struct clip_ctx * ctx, const int n_thread
 
 // ---- encoders: host-pointer forms (the reference API) ----
 bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_image_f32_batch * imgs, float * vec,
-                             const bool normalize) {
+                             const bool normalize) try {
     (void)n_threads;
     clip_ctx * ctx = const_cast<clip_ctx *>(cctx);  // const handle, mutable workspace — as in the reference
     if (!ctx->has_vision_encoder) {
@@ -190,7 +192,7 @@ bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, 
     if (!ok) fprintf(stderr, "clip_image_batch_encode: HIP error: %s\n", hipGetErrorString(hipGetLastError()));
     if (ctx->profiling) prof_collect(ctx);
     return ok;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_image_batch_encode: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_image_batch_encode: unknown exception\n"); return false; }
 
 bool clip_image_encode(const struct clip_ctx * ctx, const int n_threads, struct clip_image_f32 * img, float * vec, const bool normalize) {
     if (!ctx->has_vision_encoder) {
@@ -214,7 +216,7 @@ bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct 
 // raw u8 images -> embeddings with the resize/crop/normalise on the GPU (bit-identical to clip_image_preprocess):
 // ships <= 3 B/pixel of the ORIGINAL image instead of 12 B/pixel of the resized one and takes the double-precision
 // resampling (the dominant host cost of benchmark.cpp / zsl.cpp style callers) off the CPU.
-bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * vec, bool normalize) {
+bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * vec, bool normalize) try {
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
         return false;
@@ -250,10 +252,10 @@ bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_ima
     if (!ok) fprintf(stderr, "clip_amd_image_batch_encode_u8: failed (%s)\n", hipGetErrorString(hipGetLastError()));
     if (ctx->profiling) prof_collect(ctx);
     return ok;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_amd_image_batch_encode_u8: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_amd_image_batch_encode_u8: unknown exception\n"); return false; }
 
 bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_tokens * tokens, size_t n_texts, float * vec,
-                            const bool normalize) {
+                            const bool normalize) try {
     (void)n_threads;
     clip_ctx * ctx = const_cast<clip_ctx *>(cctx);
     if (!ctx->has_text_encoder) {
@@ -285,7 +287,7 @@ bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, c
     ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (ctx->profiling) prof_collect(ctx);
     return ok;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_text_batch_encode: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_text_batch_encode: unknown exception\n"); return false; }
 
 bool clip_text_encode(const struct clip_ctx * ctx, const int n_threads, const struct clip_tokens * tokens, float * vec, const bool normalize) {
     if (!ctx->has_text_encoder) {
@@ -308,7 +310,7 @@ float clip_similarity_score(const float * vec1, const float * vec2, const int ve
 }
 
 bool clip_compare_text_and_image(const struct clip_ctx * ctx, const int n_threads, const char * text, const struct clip_image_u8 * image,
-                                 float * score) {
+                                 float * score) try {
     if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
         printf("clip_compare_text_and_image function can only be used with two-tower models\n");
         return false;
@@ -326,7 +328,7 @@ bool clip_compare_text_and_image(const struct clip_ctx * ctx, const int n_thread
     if (!ok) return false;
     *score = clip_similarity_score(img_vec.data(), txt_vec.data(), dim);
     return true;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_compare_text_and_image: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_compare_text_and_image: unknown exception\n"); return false; }
 
 bool softmax_with_sorting(float * arr, const int length, float * sorted_scores, int * indices) {
     if (length < 0) return false;
@@ -350,7 +352,7 @@ bool softmax_with_sorting(float * arr, const int length, float * sorted_scores, 
 }
 
 bool clip_zero_shot_label_image(struct clip_ctx * ctx, const int n_threads, const struct clip_image_u8 * input_img, const char ** labels,
-                                const size_t n_labels, float * scores, int * indices) {
+                                const size_t n_labels, float * scores, int * indices) try {
     if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
         printf("clip_zero_shot_label_image function can only be used with two-tower models\n");
         return false;
@@ -373,7 +375,7 @@ bool clip_zero_shot_label_image(struct clip_ctx * ctx, const int n_threads, cons
     if (!clip_text_batch_encode(ctx, n_threads, toks.data(), n_labels, txt.data(), false)) return false;
     for (size_t i = 0; i < n_labels; i++) sims[i] = clip_similarity_score(img_vec.data(), txt.data() + i * dim, dim);
     return softmax_with_sorting(sims.data(), (int)n_labels, scores, indices);
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_zero_shot_label_image: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_zero_shot_label_image: unknown exception\n"); return false; }
 
 // ---- batched zero-shot on the GPU: preprocessing, both towers and the scoring stay on the device ----
 bool clip_amd_zero_shot_score_device(struct clip_ctx * ctx, const float * d_img, int n_images, const float * d_txt, int n_labels, int dim,
@@ -390,7 +392,7 @@ bool clip_amd_zero_shot_score_device(struct clip_ctx * ctx, const float * d_img,
 }
 
 bool clip_amd_zero_shot_label_images(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n_images, const char ** labels,
-                                     size_t n_labels, float * scores, int * indices) {
+                                     size_t n_labels, float * scores, int * indices) try {
     if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
         printf("clip_zero_shot_label_image function can only be used with two-tower models\n");
         return false;
@@ -431,10 +433,10 @@ bool clip_amd_zero_shot_label_images(struct clip_ctx * ctx, const struct clip_im
     }
     if (ctx->profiling) prof_collect(ctx);
     return ok;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_amd_zero_shot_label_images: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_amd_zero_shot_label_images: unknown exception\n"); return false; }
 
 // ---- quantizer (reference clip.cpp:1661-1844): re-emit the GGUF with 2-D "*weight" tensors quantised ----
-bool clip_model_quantize(const char * fname_inp, const char * fname_out, const int itype) {
+bool clip_model_quantize(const char * fname_inp, const char * fname_out, const int itype) try {
     switch (itype) {
     case 2: case 3: case 6: case 7: case 8: break;
     default:
@@ -493,7 +495,7 @@ bool clip_model_quantize(const char * fname_inp, const char * fname_out, const i
     printf("%s: original size  = %8.2f MB\n", "clip_model_quantize", total_org / 1024.0 / 1024.0);
     printf("%s: quantized size  = %8.2f MB\n", "clip_model_quantize", total_new / 1024.0 / 1024.0);
     return true;
-}
+} catch (const std::exception & e) { fprintf(stderr, "clip_model_quantize: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_model_quantize: unknown exception\n"); return false; }
 
 // ---- profiling ----
 void clip_amd_profile_enable(struct clip_ctx * ctx, bool on) {
@@ -541,7 +543,11 @@ int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches,
     return n;
 }
 
-// ---- kernel-level test hooks ----
+// ---- kernel-level test hooks (compiled out with -DCLIPAMD_TEST_HOOKS=0: `make hooks=0`) ----
+#ifndef CLIPAMD_TEST_HOOKS
+#define CLIPAMD_TEST_HOOKS 1
+#endif
+#if CLIPAMD_TEST_HOOKS
 // Extended form: qcols / qscale (EPI_F16 Q-scale path, clip.cpp:1363) and epilogue 5 = EPI_PATCH_F32 (patch embedding:
 // row m of the GEMM lands in output row (m / Np) * T + 1 + m % Np and gets pos[1 + m % Np] added; no bias; the class-token
 // rows (b * T) are left untouched).  For epilogue 5, y is [(M / Np) * T][N] and pos is [T][N].
@@ -706,5 +712,7 @@ int clip_amd_test_attention(const float * qkv, int nseq, int T, int h, int n_hea
     (void)hipMemcpy(out, o32.p, rows * h * 4, hipMemcpyDeviceToHost);
     return 0;
 }
+
+#endif  // CLIPAMD_TEST_HOOKS
 
 }  // extern "C"

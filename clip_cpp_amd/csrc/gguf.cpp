@@ -129,7 +129,7 @@ bool GgufFile::open(const char * path, std::string & err) {
             v.count = c.rd<uint64_t>();
             if (!c.ok) break;
             if (v.elem_type == GV_STR) {
-                if (v.count > (1u << 26)) { c.ok = false; break; }
+                if (v.count > (1u << 26) || v.count > (uint64_t)(c.end - c.p) / 8) { c.ok = false; break; }   // every string costs >= 8 bytes (its length)
                 v.strs.reserve((size_t)v.count);
                 for (uint64_t j = 0; j < v.count && c.ok; j++) v.strs.push_back(c.str());
             } else {
@@ -165,16 +165,28 @@ bool GgufFile::open(const char * path, std::string & err) {
         if (!c.ok) break;
         for (int d = 0; d < 4; d++)
             if (t.ne[d] <= 0 || t.ne[d] > (1ll << 32)) c.ok = false;
+        if (!c.ok) break;
+        // element / byte counts with overflow checks: four dims of up to 2^32 each would wrap int64 (a wrapped size passes the
+        // bounds check below); no tensor of a real file is anywhere near the file size, so bound the running product by it
+        unsigned __int128 nel = 1;
+        for (int d = 0; d < 4; d++) {
+            nel *= (unsigned __int128)t.ne[d];
+            if (nel > ((unsigned __int128)map_size_ << 3)) { err = "tensor " + t.name + ": shape larger than the file"; return false; }   // >= 1 bit per element
+        }
         const size_t rb = ggml_row_bytes(t.type, t.ne[0]);
         if (rb == 0) { err = "tensor " + t.name + ": unsupported type/shape"; return false; }
-        t.nbytes = rb * (size_t)t.nrows();
+        const unsigned __int128 nb = (unsigned __int128)rb * (unsigned __int128)(nel / (unsigned __int128)t.ne[0]);
+        if (nb > (unsigned __int128)map_size_) { err = "tensor " + t.name + " is larger than the file"; return false; }
+        t.nbytes = (size_t)nb;
         tensor_index_[t.name] = i;
     }
     if (!c.ok) { err = "corrupt GGUF tensor-info section"; return false; }
     const uint64_t pos = (uint64_t)(c.p - base);
     data_offset = (pos + alignment - 1) / alignment * alignment;
+    if (data_offset > map_size_) { err = "tensor data section starts past end of file"; return false; }
     for (auto & t : tensors) {
-        if (data_offset + t.offset + t.nbytes > map_size_) { err = "tensor " + t.name + " extends past end of file"; return false; }
+        // no wrap-around: offset and nbytes are each checked against what is left of the file
+        if (t.offset > map_size_ - data_offset || t.nbytes > map_size_ - data_offset - t.offset) { err = "tensor " + t.name + " extends past end of file"; return false; }
         t.data = base + data_offset + t.offset;
     }
     return true;

@@ -216,14 +216,18 @@ clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
     if (n_devices <= 0) n_devices = ndev;
-    if (ndev <= 0 || n_devices > ndev) {
+    // CLIP_AMD_MULTI_OVERSUBSCRIBE=1 (test aid for 1-GPU machines): replicas beyond the device count share devices (g % ndev); the
+    // collective is then replaced by per-replica device-to-host copies (RCCL refuses two ranks on one device)
+    const char * over = getenv("CLIP_AMD_MULTI_OVERSUBSCRIBE");
+    const bool oversub = over && over[0] == '1' && ndev > 0 && n_devices > ndev;
+    if (ndev <= 0 || (n_devices > ndev && !oversub)) {
         fprintf(stderr, "clip_amd_model_load_multi: %d devices requested, %d visible\n", n_devices, ndev);
         return nullptr;
     }
     MultiCtx * mc = new MultiCtx();
     mc->G = n_devices;
     for (int g = 0; g < n_devices; g++) {
-        clip_ctx * c = load_model(fname, g == 0 ? verbosity : 0, g);
+        clip_ctx * c = load_model(fname, g == 0 ? verbosity : 0, g % ndev);
         if (!c) {
             for (clip_ctx * r : mc->rep) free_model(r);
             delete mc;
@@ -235,7 +239,7 @@ clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
     mc->send_floats.assign(n_devices, 0); mc->recv_floats.assign(n_devices, 0);
     if (n_devices > 1) {
         const char * e = getenv("CLIP_AMD_MULTI_NO_RCCL");   // debugging aid: G device-to-host copies into disjoint slices instead of the all-gather
-        mc->use_rccl = !(e && e[0] == '1');
+        mc->use_rccl = !(e && e[0] == '1') && !oversub;
         if (mc->use_rccl) {
             std::vector<int> devs(n_devices);
             for (int g = 0; g < n_devices; g++) devs[g] = g;

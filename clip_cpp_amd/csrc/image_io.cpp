@@ -5,6 +5,7 @@
 // progressive Huffman).
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,14 +42,17 @@ bool decode_pnm(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
         if (d[p] == '#') { while (p < d.size() && d[p] != '\n') p++; continue; }
         if (d[p] == ' ' || d[p] == '\t' || d[p] == '\n' || d[p] == '\r') { p++; continue; }
         int v = 0, nd = 0;
-        while (p < d.size() && d[p] >= '0' && d[p] <= '9') { v = v * 10 + (d[p] - '0'); p++; nd++; }
+        while (p < d.size() && d[p] >= '0' && d[p] <= '9') {
+            if (v > 100000000) return false;           // absurd header value: no signed overflow on long digit runs
+            v = v * 10 + (d[p] - '0'); p++; nd++;
+        }
         if (!nd) return false;
         vals[got++] = v;
     }
     if (got < 3 || p >= d.size()) return false;
     p++;  // single whitespace after maxval
     nx = vals[0]; ny = vals[1];
-    if (nx <= 0 || ny <= 0 || vals[2] != 255) return false;
+    if (nx <= 0 || ny <= 0 || vals[2] != 255 || (size_t)nx * (size_t)ny > ((size_t)1 << 28)) return false;
     const size_t need = (size_t)nx * ny * ch;
     if (d.size() - p < need) return false;
     rgb.resize((size_t)nx * ny * 3);
@@ -65,8 +69,9 @@ bool decode_bmp(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
     auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, &d[o], 2); return v; };
     const uint32_t off = u32(10);
     const int w = i32(18), hh = i32(22), bpp = u16(28);
-    if (u32(30) != 0 || (bpp != 24 && bpp != 32) || w <= 0 || hh == 0) return false;
+    if (u32(30) != 0 || (bpp != 24 && bpp != 32) || w <= 0 || hh == 0 || hh == INT32_MIN) return false;
     const int h = hh < 0 ? -hh : hh;
+    if ((size_t)w * (size_t)h > ((size_t)1 << 28)) return false;
     const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
     if (d.size() < off + stride * h) return false;
     nx = w; ny = h;

@@ -384,6 +384,7 @@ struct Decoder {
         if (ncomp != 1 && ncomp != 3) return fail("unsupported component count (CMYK?)");
         if (len != 6 + 3 * ncomp) return fail("bad SOF length");
         if ((size_t)width * height > ((size_t)1 << 28)) return fail("image too large");
+        hmax = vmax = 1;                                   // a second SOF must not inherit the first one's maxima
         for (int i = 0; i < ncomp; i++) {
             Component & c = comp[i];
             c.id = get8();

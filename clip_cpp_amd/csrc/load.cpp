@@ -241,6 +241,20 @@ bool kv_u32(const GgufFile & g, const std::string & key, int32_t & out, std::str
     return true;
 }
 
+// What the kernels support, checked at load time so that an unsupported model fails HERE with a clear message instead of loading
+// and then producing garbage or failing at the first encode: LayerNorm holds a row in <= 8 x 256 floats; epilogues
+// store 4 columns per lane; the attention kernel is instantiated for d_head in {32, 64, 80, 96} and <= 592 (d_head <= 64) or 288 keys.
+std::string kernel_limits(const char * tower, int hidden, int n_head, int proj, int seq_len) {
+    char buf[192];
+    const int dh = hidden / n_head;
+    if (hidden > 2048) { snprintf(buf, sizeof buf, "unsupported %s hparams: hidden_size %d > 2048", tower, hidden); return buf; }
+    if (proj <= 0 || proj % 4) { snprintf(buf, sizeof buf, "unsupported %s hparams: projection_dim %d is not a multiple of 4", tower, proj); return buf; }
+    if (dh != 32 && dh != 64 && dh != 80 && dh != 96) { snprintf(buf, sizeof buf, "unsupported %s hparams: head size %d (supported: 32, 64, 80, 96)", tower, dh); return buf; }
+    const int max_len = dh <= 64 ? 592 : 288;
+    if (seq_len > max_len) { snprintf(buf, sizeof buf, "unsupported %s hparams: %d tokens per sequence > %d (head size %d)", tower, seq_len, max_len, dh); return buf; }
+    return std::string();
+}
+
 }  // namespace
 
 clip_ctx * load_model(const char * fname, int verbosity, int device) {
@@ -310,6 +324,7 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         }
         if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64)
             return fail("unsupported text hparams (hidden/ff must be multiples of 64)");
+        { const std::string why = kernel_limits("text", hp.hidden_size, hp.n_head, hp.projection_dim, hp.num_positions); if (!why.empty()) return fail(why); }
         if (verbosity >= 2) {
             printf("\n%s: text model hparams\n", "clip_model_load");
             printf("n_vocab            %d\nnum_positions      %d\nt_hidden_size      %d\nt_n_intermediate   %d\n", hp.n_vocab, hp.num_positions, hp.hidden_size, hp.n_intermediate);
@@ -341,6 +356,7 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64 ||
             hp.patch_size <= 0 || hp.image_size % hp.patch_size)
             return fail("unsupported vision hparams (hidden/ff must be multiples of 64)");
+        { const int g_ = hp.image_size / hp.patch_size; const std::string why = kernel_limits("vision", hp.hidden_size, hp.n_head, hp.projection_dim, g_ * g_ + 1); if (!why.empty()) return fail(why); }
         if (verbosity >= 2) {
             printf("\n%s: vision model hparams\n", "clip_model_load");
             printf("image_size         %d\npatch_size         %d\nv_hidden_size      %d\nv_n_intermediate   %d\n", hp.image_size, hp.patch_size, hp.hidden_size, hp.n_intermediate);

@@ -251,3 +251,49 @@ def test_product_side_synthetic_models_load_everywhere(tmp_path, clip_lib):
     finally:
         if env_had is None:
             os.environ.pop("CLIP_AMD_ALLOW_NO_DEVICE", None)
+
+
+def test_malformed_and_unsupported_files_are_rejected_at_load(clip_lib, tmp_path, host_only_env, capfd):
+    """(a) tensor shapes whose element count wraps int64 must not pass the bounds check; (b) models outside the
+    kernels' limits (hidden_size > 2048, projection_dim % 4, unsupported head size, too many tokens) fail at LOAD with a message,
+    not at the first encode; (c) nothing throws across the C ABI (quantising such a file returns false)."""
+    import struct
+    L = clip_lib.lib()
+
+    def s(b):
+        return struct.pack("<Q", len(b)) + b
+
+    # (a) one tensor with dims 2^32 x 2^32 x 2^32 x 2^32 (product wraps to 0), offset 0
+    kv = s(b"general.alignment") + struct.pack("<II", 4, 32)
+    ti = s(b"t.weight") + struct.pack("<I", 4) + struct.pack("<QQQQ", 1 << 32, 1 << 32, 1 << 32, 1 << 32) + struct.pack("<IQ", 0, 0)
+    blob = b"GGUF" + struct.pack("<IQQ", 2, 1, 1) + kv + ti + b"\0" * 256
+    f = tmp_path / "wrap.gguf"
+    f.write_bytes(blob)
+    assert not L.clip_model_load(os.fsencode(str(f)), 0)
+    assert not L.clip_model_quantize(os.fsencode(str(f)), os.fsencode(str(tmp_path / "o.gguf")), 2)
+    # offset + size wrap: huge offset
+    ti2 = s(b"t.weight") + struct.pack("<I", 1) + struct.pack("<Q", 64) + struct.pack("<IQ", 0, (1 << 64) - 64)
+    f2 = tmp_path / "wrap2.gguf"
+    f2.write_bytes(b"GGUF" + struct.pack("<IQQ", 2, 1, 1) + kv + ti2 + b"\0" * 512)
+    assert not L.clip_model_load(os.fsencode(str(f2)), 0)
+    # string array whose count exceeds the remaining bytes
+    kv3 = s(b"tokenizer.ggml.tokens") + struct.pack("<IIQ", 9, 8, 1 << 25)
+    f3 = tmp_path / "arr.gguf"
+    f3.write_bytes(b"GGUF" + struct.pack("<IQQ", 2, 0, 1) + kv3 + b"\0" * 64)
+    assert not L.clip_model_load(os.fsencode(str(f3)), 0)
+    capfd.readouterr()
+
+    # (b) kernel limits
+    base = fixtures.CONFIGS["tiny"]
+    cases = {
+        "hidden_size 4096 > 2048": dict(v=dict(base["v"], h=4096, nh=64, ff=64), t=base["t"]),
+        "projection_dim 30": dict(v=dict(base["v"], proj=30), t=dict(base["t"], proj=30)),
+        "head size 16": dict(v=dict(base["v"], nh=4), t=base["t"]),
+        "tokens per sequence": dict(v=dict(base["v"], S=336, P=8, h=192, nh=2, ff=64), t=base["t"]),   # 42*42+1 = 1765 tokens, d_head 96
+    }
+    for needle, cfg in cases.items():
+        path = str(tmp_path / ("lim_%d.gguf" % len(needle)))
+        fixtures.make_model(path, cfg, "f32", text="projection" in needle, vision=True)
+        assert not L.clip_model_load(os.fsencode(path), 0), needle
+        err = capfd.readouterr().err
+        assert needle in err, (needle, err)

@@ -1,0 +1,74 @@
+"""Multi-GPU form of clip_image_batch_encode behind the C ABI (clip_amd_model_load_multi): shard arithmetic on CPU;
+on the GPU tier the sharded path itself — replicas, per-replica host threads, padding of the last shard — runs on ONE device with
+over-subscribed replicas (the collective is replaced by per-replica copies there: RCCL refuses two ranks on one device), and with
+the real ncclAllGather when >= 2 devices are visible."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fixtures
+
+
+def test_shard_bounds_are_contiguous_ceil_shards(clip_lib):
+    for total in (0, 1, 5, 8, 13, 256, 1000, 1024, 1023):
+        for G in (1, 2, 3, 4, 8):
+            spans = [clip_lib.shard_bounds(total, G, g) for g in range(G)]
+            per = -(-total // G) if total else 0
+            assert all(s[2] == per for s in spans)
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+            assert all(0 <= hi - lo <= per for lo, hi, _ in spans)
+            # only trailing shards are short: every shard before the first short one is full
+            sizes = [hi - lo for lo, hi, _ in spans]
+            first_short = next((i for i, s in enumerate(sizes) if s < per), G)
+            assert all(s == per for s in sizes[:first_short]) and all(s == 0 for s in sizes[first_short + 1:])
+    assert clip_lib.shard_bounds(10, 0, 0) == (0, 0, 0) and clip_lib.shard_bounds(10, 4, 7) == (0, 0, 0)   # invalid arguments
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,B", [(1, 7), (2, 7), (3, 8), (4, 5), (2, 300)])
+def test_sharded_batch_encode_matches_single_context(clip_lib, fixture_cache, G, B, monkeypatch):
+    if clip_lib.device_count() < 1:
+        pytest.fail("GPU tier needs a HIP device")
+    if clip_lib.device_count() < G:
+        monkeypatch.setenv("CLIP_AMD_MULTI_OVERSUBSCRIBE", "1")
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=True, vision=True)
+    single = clip_lib.Clip(p, device=0)
+    multi = clip_lib.Clip(p, n_devices=G)
+    assert multi.n_devices == G and single.n_devices == 1
+    imgs = fixtures.synthetic_images(B, 32, seed=5)
+    want = single.encode_images(imgs)
+    got = multi.encode_images(imgs)                         # B >= 2 G: sharded, ceil(B / G) per replica, last shard padded
+    assert np.array_equal(got, want)
+    assert np.array_equal(multi.encode_images(imgs[:1]), want[:1])      # tiny batch: device 0 only
+    # everything else of the API keeps working on the primary context
+    ids = [49406, 5, 6, 7, 49407]
+    assert np.array_equal(np.asarray(multi.encode_text(ids), np.float32), np.asarray(single.encode_text(ids), np.float32))
+    multi.close()
+    single.close()
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_path_with_two_devices(clip_lib, fixture_cache):
+    if clip_lib.device_count() < 2:
+        pytest.skip("needs >= 2 visible HIP devices (the 1-GPU box runs the over-subscribed form above)")
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=False, vision=True)
+    G = min(clip_lib.device_count(), 8)
+    single = clip_lib.Clip(p, device=0)
+    multi = clip_lib.Clip(p, n_devices=G)
+    for B in (2 * G, 5 * G + 3, 1024):
+        imgs = fixtures.synthetic_images(B, 32, seed=B)
+        want = single.encode_images(imgs)
+        assert np.array_equal(multi.encode_images(imgs), want)
+        lo, hi, per = clip_lib.shard_bounds(B, G, 0)
+        # the gathered [G * per][proj] buffer on EVERY device holds the whole result (one ncclAllGather)
+        for g in range(G):
+            ptr = clip_lib.lib().clip_amd_gathered_embeddings(multi.ctx, g)
+            assert ptr
+            with torch.cuda.device(g):
+                t = torch.empty((B, 32), dtype=torch.float32, device="cuda:%d" % g)
+                C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), B * 32 * 4, 3)
+                assert np.array_equal(t.cpu().numpy(), want)
