@@ -681,6 +681,66 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     return ms < 0 ? -4.f : ms * 1000.f / iters;
 }
 
+// Small-M kernel (k_skinny.hip) on host data: y[M][N] = epilogue(A . W^T + bias), M <= 64.  ln_w != NULL: A = LayerNorm(x) fused in
+// the kernel (row statistics via launch_row_stats, as forward.cpp does for the first layer); else A = fp16(x).
+// epilogue: 0 f32, 1 f16 (+ qcols / qscale), 2 gelu, 3 quick-gelu, 4 residual (also returns the partial row statistics it leaves:
+// stats_out [N/16][128][2], may be NULL).  Returns 0, or -5 when the combination is not covered by the skinny path.
+int clip_amd_test_skinny(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias, const float * resid,
+                         const float * ln_w, const float * ln_b, float eps, float * y, int epilogue, int qcols, float qscale, float * stats_out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return -1; }
+    DevWeight W;
+    void * wbase = nullptr;
+    if (!repack_for_test(type, w_raw, N, K, W, &wbase)) return -2;
+    const int Kpad = W.Kpad;
+    DBuf dx32((size_t)M * K * 4), dx16((size_t)(M + 1) * Kpad * 2), dbias((size_t)N * 4), dout((size_t)M * N * 4), dout32((size_t)M * N * 4), dlw((size_t)K * 4), dlb((size_t)K * 4),
+        dst((size_t)2 * 128 * 128 * 8);
+    hipStream_t s = nullptr;
+    (void)hipMemcpy(dx32.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice);
+    if (bias) (void)hipMemcpy(dbias.p, bias, (size_t)N * 4, hipMemcpyHostToDevice);
+    (void)hipMemset(dst.p, 0, (size_t)2 * 128 * 128 * 8);
+    SkinnyParams p;
+    p.M = (int)M; p.W = W; p.bias = bias ? (const float *)dbias.p : nullptr; p.ldc = (int)N; p.qcols = qcols; p.qscale = qscale;
+    if (ln_w) {
+        (void)hipMemcpy(dlw.p, ln_w, (size_t)K * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dlb.p, ln_b, (size_t)K * 4, hipMemcpyHostToDevice);
+        launch_row_stats((const float *)dx32.p, (int)K, (int)M, (int)K, (float2 *)dst.p, s);
+        p.x32 = (const float *)dx32.p; p.ldx = (int)K; p.ln_w = (const float *)dlw.p; p.ln_b = (const float *)dlb.p; p.eps = eps;
+        p.stats_in = (const float2 *)dst.p; p.stats_slots = 1;
+    } else {
+        launch_f32_to_f16((const float *)dx32.p, (int)K, (half_t *)dx16.p, Kpad, (int)M, (int)K, Kpad, s);
+        p.A16 = (const half_t *)dx16.p; p.lda = Kpad;
+    }
+    int epi = EPI_F32;
+    switch (epilogue) {
+    case 0: epi = EPI_F32; p.out = dout32.p; break;
+    case 1: epi = EPI_F16; p.out = dout.p; break;
+    case 2: epi = EPI_GELU_F16; p.out = dout.p; break;
+    case 3: epi = EPI_QGELU_F16; p.out = dout.p; break;
+    case 4:
+        epi = EPI_RESID_F32;
+        (void)hipMemcpy(dout32.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice);
+        p.out = dout32.p; p.resid = (const float *)dout32.p;
+        p.stats_out = (float2 *)dst.p + 128 * 128;
+        break;
+    default: (void)hipFree(wbase); return -3;
+    }
+    int rc = 0;
+    if (!skinny_supported(p, epi)) rc = -5;
+    else {
+        launch_skinny(p, epi, s);
+        if (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16)
+            launch_f16_to_f32((const half_t *)dout.p, (int)N, (float *)dout32.p, (int)N, (int)M, (int)N, s);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = -4;
+        else {
+            (void)hipMemcpy(y, dout32.p, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+            if (stats_out && epi == EPI_RESID_F32) (void)hipMemcpy(stats_out, (float2 *)dst.p + 128 * 128, (size_t)128 * 128 * 8, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(wbase);
+    return rc;
+}
+
 int clip_amd_test_layernorm(const float * x, const float * w, const float * b, float eps, int64_t rows, int64_t h, float * y, int out_f16) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return -1; }

@@ -125,6 +125,66 @@ LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows) {
     return lp;
 }
 
+// ---- small-M path (rows <= 64: one ViT-B/32 image, one text, a few short labels): k_skinny.hip, 5 launches per layer ----
+bool skinny_enabled() {
+    static int on = -1;
+    if (on < 0) { const char * e = getenv("CLIP_AMD_SKINNY"); on = !(e && e[0] == '0'); }
+    return on != 0;
+}
+
+void skinny(clip_ctx * ctx, const char * what, const SkinnyParams & p, int epi) {
+    if (!ctx->profiling) { launch_skinny(p, epi, ctx->stream); return; }
+    char fam[96];
+    snprintf(fam, sizeof fam, "skinny_kernel<%d,%d,%s>/%s", p.W.wtype, epi, p.x32 ? "ln" : "f16", what);
+    const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
+    const double by = weight_bytes(p.W) + (double)p.M * p.W.K * (p.x32 ? 4 : 2) + (double)p.M * p.W.N * (epi == EPI_RESID_F32 ? 8 : epi == EPI_F32 || epi == EPI_PATCH_F32 ? 4 : 2);
+    ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
+    launch_skinny(p, epi, ctx->stream);
+}
+
+bool layers_fit_skinny(const DevTower & tw, int rows, int h, int ff) {
+    if (!skinny_enabled() || rows <= 0 || rows > 64 || h > 2048 || h % 16 || h / 16 > 128 || tw.layers.empty()) return false;
+    const DevLayer & l = tw.layers[0];
+    return l.qkv.K == l.qkv.Kpad && l.ff1.K == l.ff1.Kpad && l.o.N == h && l.ff2.N == h && l.ff1.N == ff;
+}
+
+// precondition: slot 0 of ctx->sk_stats holds the row statistics of x (launch_row_stats)
+bool run_layers_skinny(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
+                       const int * d_seq_start, int max_len, bool causal, float * x, half_t * qkv, half_t * att, half_t * mid) {
+    hipStream_t s = ctx->stream;
+    const int dh = h / nh;
+    const float qscale = 1.0f / sqrtf((float)dh);
+    const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    float2 * stA = ctx->sk_stats, * stB = ctx->sk_stats + 128 * 128;
+    int slotsA = 1;
+    for (const DevLayer & l : tw.layers) {
+        SkinnyParams q;   // LN1 + q/k/v projection (+ Q scale after the bias, clip.cpp:1363)
+        q.x32 = x; q.ldx = h; q.ln_w = l.ln1_w; q.ln_b = l.ln1_b; q.eps = eps; q.stats_in = stA; q.stats_slots = slotsA;
+        q.M = rows; q.W = l.qkv; q.bias = l.qkv_b; q.out = qkv; q.ldc = 3 * h; q.qscale = qscale; q.qcols = h;
+        skinny(ctx, "ln1_qkv", q, EPI_F16);
+        {
+            const double afl = 4.0 * (double)nseq * nh * (double)max_len * max_len * dh;
+            ProfScope ps(ctx, "attention", nseq * nh, max_len, dh, afl, (double)rows * h * 8);
+            if (!launch_attention(qkv, att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s)) {
+                fprintf(stderr, "clip (hip): attention kernel does not support T=%d d_head=%d\n", max_len, dh);
+                return false;
+            }
+        }
+        SkinnyParams o;   // out-projection + residual; leaves the statistics of the new rows for LN2
+        o.A16 = att; o.lda = h; o.M = rows; o.W = l.o; o.bias = l.o_b; o.out = x; o.ldc = h; o.resid = x; o.stats_out = stB;
+        skinny(ctx, "out_resid", o, EPI_RESID_F32);
+        SkinnyParams u;   // LN2 + FFN-up + activation
+        u.x32 = x; u.ldx = h; u.ln_w = l.ln2_w; u.ln_b = l.ln2_b; u.eps = eps; u.stats_in = stB; u.stats_slots = h / 16;
+        u.M = rows; u.W = l.ff1; u.bias = l.ff1_b; u.out = mid; u.ldc = ff;
+        skinny(ctx, "ln2_ffn_up", u, act);
+        SkinnyParams d;   // FFN-down + residual; statistics for the next layer's LN1
+        d.A16 = mid; d.lda = ff; d.M = rows; d.W = l.ff2; d.bias = l.ff2_b; d.out = x; d.ldc = h; d.resid = x; d.stats_out = stA;
+        skinny(ctx, "ffn_down_resid", d, EPI_RESID_F32);
+        slotsA = h / 16;
+    }
+    return true;
+}
+
 // L x { LN1, QKV, attention, out-proj(+res), LN2, FFN-up(+act), FFN-down(+res) }   (clip.cpp:1342-1423 / :1064-1143)
 bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
                 const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid) {
@@ -361,7 +421,10 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 8);
             launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);  // pre-LN (:1334-1339)
         }
-        if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid)) return false;
+        if (layers_fit_skinny(V, rows, h, ff)) {
+            launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
+            if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, qkv, att, mid)) return false;
+        } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid)) return false;
         // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
         launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, pooled, h, nullptr, 0, s);
         GemmParams pj;
@@ -446,7 +509,10 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     }
     auto launch_all = [&]() -> bool {
         launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
-        if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
+        if (layers_fit_skinny(Tw, rows, h, ff)) {
+            launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
+            if (!run_layers_skinny(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, qkv, att, mid)) return false;
+        } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
         // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
         launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
         GemmParams pj;

@@ -95,6 +95,35 @@ void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream
 struct DequantJobs { DevWeight W[4]; half_t * out[4]; int blk_end[4]; int n = 0; };
 void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, hipStream_t stream);
 
+// k_skinny.hip: latency-oriented weight GEMM for M <= 64 rows (one image, one text): N / 16 workgroups, weights dequantised in
+// registers straight from the planes, intra-workgroup split-K, optional LayerNorm fused on the A operand (A = LN(x32) with row
+// statistics taken from the producer's partial slots) and partial statistics of the new residual rows out of EPI_RESID_F32.
+struct SkinnyParams {
+    const half_t * A16 = nullptr;   // fp16 activations [M][lda] ...
+    int lda = 0;
+    const float * x32 = nullptr;    // ... or the f32 residual stream [M][ldx], normalised on the fly with ln_w / ln_b / eps
+    int ldx = 0;
+    const float * ln_w = nullptr, * ln_b = nullptr;
+    float eps = 0.f;
+    const float2 * stats_in = nullptr;   // [row][stats_cap] partial (sum, sum of squares) of x32 rows: the first stats_slots entries of a row are valid
+    int stats_slots = 0;
+    int M = 0;
+    DevWeight W;
+    const float * bias = nullptr;
+    void * out = nullptr;
+    int ldc = 0;
+    const float * resid = nullptr;
+    float qscale = 1.0f;
+    int qcols = 0;
+    int Np = 0, T = 0;
+    const float * pos = nullptr;
+    float2 * stats_out = nullptr;        // EPI_RESID_F32: [row][stats_cap], entry blockIdx.x = statistics of the row over this workgroup's 16 columns
+    int stats_cap = 128;
+};
+bool skinny_supported(const SkinnyParams & p, int epilogue);
+void launch_skinny(const SkinnyParams & p, int epilogue, hipStream_t stream);
+void launch_row_stats(const float * x, int ldx, int rows, int h, float2 * stats, hipStream_t stream);   // slot 0 := statistics of every row
+
 // LayerNorm over rows of h floats (ggml_norm + mul + add, reference clip.cpp:1350-1355).
 // Row r reads x[in_rows[r]] when in_rows != nullptr, else x[r * in_row_mul] (strided gather, e.g. the
 // CLS rows b*T); out16/out32 may be null.

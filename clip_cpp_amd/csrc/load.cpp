@@ -407,6 +407,7 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         if (hipMalloc(&w, nfl * sizeof(float)) != hipSuccess || hipMalloc(&c, 4096 * sizeof(unsigned)) != hipSuccess || hipMemset(c, 0, 4096 * sizeof(unsigned)) != hipSuccess)
             return fail("hipMalloc (split-K workspace) failed");
         ctx->sk_ws = (float *)w; ctx->sk_ws_floats = nfl; ctx->sk_cnt = (unsigned *)c; ctx->sk_cnt_n = 4096;
+        if (hipMalloc((void **)&ctx->sk_stats, (size_t)2 * 128 * 128 * sizeof(float2)) != hipSuccess) return fail("hipMalloc (LayerNorm statistics) failed");
     }
     ctx->weights_bytes = L.st.buf.size() + 256;
     if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");
@@ -438,6 +439,7 @@ void free_model(clip_ctx * ctx) {
         if (ctx->io_out) (void)hipFree(ctx->io_out);
         if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
         if (ctx->w16_panel) (void)hipFree(ctx->w16_panel);
+        if (ctx->sk_stats) (void)hipFree(ctx->sk_stats);
         if (ctx->sk_ws) (void)hipFree(ctx->sk_ws);
         if (ctx->sk_cnt) (void)hipFree(ctx->sk_cnt);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -118,6 +118,9 @@ struct clip_ctx {
     size_t sk_ws_floats = 0;
     unsigned * sk_cnt = nullptr;
     int sk_cnt_n = 0;
+    // LayerNorm partial statistics of the small-M path (k_skinny.hip): two [128 slots][128 rows] float2 buffers, written by the
+    // residual epilogues and read by the LayerNorm-fused projections of the next sub-layer
+    float2 * sk_stats = nullptr;
     // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
     clipamd::half_t * w16_panel = nullptr;
     size_t w16_panel_halfs = 0;

@@ -121,6 +121,14 @@ int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, co
 /* Average device time (microseconds, HIP events) of one GEMM shape through the production kernel on random
  * weights of ggml type `type`; < 0 on error.  Used by scripts/gemm_bench.py for kernel A/B work. */
 float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters);
+/* Small-M kernel (M <= 64 rows: one image / one text; k_skinny.hip): y[M][N] = epilogue(A . W^T + bias) with A = fp16(x), or — ln_w
+ * != NULL — A = LayerNorm(x) fused into the kernel.  epilogue 0 f32, 1 f16 (+ qcols / qscale), 2 gelu, 3 quick-gelu, 4 residual
+ * (stats_out, if not NULL, receives the [128 rows][128 slots][2] partial row statistics the epilogue leaves for the next LayerNorm:
+ * slot j of a row = its (sum, sum of squares) over output columns 16 j .. 16 j + 15).
+ * Returns -5 when the combination is not covered by this path. */
+int clip_amd_test_skinny(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias,
+                         const float * resid, const float * ln_w, const float * ln_b, float eps, float * y, int epilogue,
+                         int qcols, float qscale, float * stats_out);
 /* y = LayerNorm(x)*w + b, rows x h. out_f16 != 0 rounds the result through fp16. */
 int clip_amd_test_layernorm(const float * x, const float * w, const float * b, float eps, int64_t rows, int64_t h,
                             float * y, int out_f16);

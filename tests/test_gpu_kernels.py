@@ -327,3 +327,76 @@ def test_gemm8_many_tiles_race_screen(L):
     base = run_gemm(L, 1, raw, N, K, X, epi=0, tile=128128)
     for _ in range(6):
         assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=160256), base)
+
+
+def run_skinny(L, tid, raw, N, K, X, bias=None, resid=None, ln=None, epi=0, qcols=0, qscale=1.0, stats=None):
+    M = X.shape[0]
+    y = np.full((M, N), np.nan, dtype=np.float32)
+    lw, lb, eps = (ln if ln is not None else (None, None, 0.0))
+    rc = L.clip_amd_test_skinny(tid, raw.ctypes.data_as(C.c_void_p), N, K, _fp(X), M, _fp(bias) if bias is not None else None,
+                                _fp(resid) if resid is not None else None, _fp(lw) if lw is not None else None,
+                                _fp(lb) if lb is not None else None, eps, _fp(y), epi, qcols, qscale, _fp(stats) if stats is not None else None)
+    assert rc == 0, "clip_amd_test_skinny rc=%d" % rc
+    return y
+
+
+@pytest.mark.parametrize("tname", TYPES[:6])
+@pytest.mark.parametrize("M,N,K", [(50, 768, 768), (1, 512, 512), (49, 1536, 512), (64, 768, 3072), (50, 2304, 768), (64, 1024, 4096), (17, 80, 64)])
+def test_skinny_gemm_vs_dequant_reference_and_tiled_kernel(L, tname, M, N, K):
+    """k_skinny.hip (M <= 128): every weight type, both wave counts (K >= 2048 -> 8 waves), both row-fragment counts (M <= 64 / <= 128),
+    f32 / residual / f16 epilogues: elementwise bound against the float64 product of the dequantised operands, and within fp32
+    re-association of the tiled kernel's result."""
+    rng = np.random.default_rng(M * 1000 + N + K)
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    Wd = ref.dequantize(tid, raw, N, K).astype(np.float64)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    Xh = _h(X).astype(np.float64)
+    lin = Xh @ Wd.T + bias
+    bound = 1.0e-3 * (np.abs(Xh) @ np.abs(Wd).T) + 1e-5
+    y = run_skinny(L, tid, raw, N, K, X, bias=bias, epi=0)
+    assert np.all(np.abs(y - lin) <= bound), np.abs(y - lin).max()
+    tiled = run_gemm(L, tid, raw, N, K, X, bias=bias, epi=0, tile=1000000 + 64064)
+    assert np.abs(y - tiled).max() <= 1e-4 * max(1.0, np.abs(tiled).max())
+    assert np.array_equal(y, run_skinny(L, tid, raw, N, K, X, bias=bias, epi=0))            # deterministic
+    stats = np.zeros((128, 128, 2), dtype=np.float32)          # [row][slot][sum, sum of squares]
+    yr = run_skinny(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=4, stats=stats)
+    assert np.all(np.abs(yr - (lin + resid)) <= bound + 1e-6 * np.abs(resid))
+    # the partial statistics the residual epilogue leaves: per row, over each workgroup's 16 columns
+    if (N + 15) // 16 <= 128:                                  # (the residual GEMMs of a model have N = hidden size <= 2048)
+        s1 = stats[:M, : (N + 15) // 16, 0].sum(1)
+        s2 = stats[:M, : (N + 15) // 16, 1].sum(1)
+        np.testing.assert_allclose(s1, yr.astype(np.float64).sum(1), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(s2, (yr.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "f16", "q5_1"])
+@pytest.mark.parametrize("M,N,K,epi", [(50, 2304, 768, 1), (50, 3072, 768, 3), (64, 2048, 512, 2), (33, 3072, 1024, 3), (1, 1280, 1280, 1)])
+def test_skinny_layernorm_fused_projection(L, tname, M, N, K, epi):
+    """LN fused on the A operand: out = act(LayerNorm(x) . W^T + b) with LayerNorm as in the standalone kernel (output rounded to fp16
+    before the product).  Reference: float64 LayerNorm -> fp16 -> float64 product; the one-pass variance and the fp16 rounding of
+    values that sit on a rounding boundary allow a few ulps of the fp16 activations."""
+    rng = np.random.default_rng(M + N + K + epi)
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    Wd = ref.dequantize(tid, raw, N, K).astype(np.float64)
+    X = (rng.standard_normal((M, K)) * 2.5 + 0.3).astype(np.float32)
+    lw = (1 + rng.standard_normal(K) * 0.05).astype(np.float32)
+    lb = (rng.standard_normal(K) * 0.05).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    xn = ref.layer_norm(X, lw, lb, 1e-5)
+    xh = _h(xn).astype(np.float64)
+    lin = xh @ Wd.T + bias
+    want = {1: lin, 2: gelu_tanh(lin), 3: gelu_quick(lin)}[epi]
+    qc, qs = ((N // 3) // 4 * 4, 0.125) if epi == 1 else (0, 1.0)       # Q-scale columns of the fused q/k/v projection
+    want = want.copy()
+    want[:, :qc] *= qs
+    y = run_skinny(L, tid, raw, N, K, X, bias=bias, ln=(lw, lb, 1e-5), epi=epi, qcols=qc, qscale=qs)
+    # LN output differs from the float64 reference by <= ~1 fp16 ulp on a few elements: bound 2^-10 * |xn| . |W|
+    bound = 2.0e-3 * (np.abs(xh) @ np.abs(Wd).T) + np.abs(want) * 2.0 ** -10 + 2e-4
+    bad = np.argwhere(np.abs(y - want) > bound)
+    assert bad.size == 0, (len(bad), np.abs(y - want).max())
+    rel = np.linalg.norm(y - want) / np.linalg.norm(want)
+    assert rel < 1e-3, rel
