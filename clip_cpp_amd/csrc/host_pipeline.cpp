@@ -89,7 +89,7 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
             return false;
         }
     }
-    const int P = std::max(1, std::min({n_threads, 16, n}));
+    const int P = std::max(1, std::min({n_threads, 16, n / 8}));   // >= 8 images (4.8 MB) per packer thread: below that the spawn costs more than the copy
     bool ok = true;
     static const bool timing = getenv("CLIP_AMD_HOST_TIMING") != nullptr;     // stderr: where a call's host time goes
     const auto t_begin = std::chrono::steady_clock::now();

@@ -20,8 +20,13 @@ SHAPES = [  # (name, M, N, K, epi)
     ("b32.b32.qkv", 1600, 2304, 768, 1), ("b32.b32.out", 1600, 768, 768, 4),
     ("txt.qkv", 10290, 1536, 512, 1), ("txt.out", 10290, 512, 512, 4), ("txt.up", 10290, 2048, 512, 3), ("txt.down", 10290, 512, 2048, 4),
     ("l14.qkv", 65792, 3072, 1024, 1), ("l14.out", 65792, 1024, 1024, 4),
+    ("l14.b32.qkv", 8224, 3072, 1024, 1), ("l14.b32.out", 8224, 1024, 1024, 4), ("l14.b32.up", 8224, 4096, 1024, 3), ("l14.b32.down", 8224, 1024, 4096, 4),
+    ("b64.qkv", 3200, 2304, 768, 1), ("b64.out", 3200, 768, 768, 4), ("b64.up", 3200, 3072, 768, 3), ("b64.down", 3200, 768, 3072, 4),
+    ("b128.qkv", 6400, 2304, 768, 1), ("b128.out", 6400, 768, 768, 4), ("b128.up", 6400, 3072, 768, 3), ("b128.down", 6400, 768, 3072, 4),
 ]
 tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
+if 'ksweep' in sys.argv[1:]:
+    tiles = [0] + [ks * 1000000 + t for t in (64064, 64128, 128128, 160128) for ks in (1, 2, 3, 4, 6, 8)]
 types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
 only = [a for a in sys.argv[1:] if "." in a]
 debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]

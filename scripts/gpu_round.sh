@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r02}
 echo "== kernels tests" ; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x 2>&1 | tail -5 | tee gpurun_out/${TAG}_kernels.log
 echo "== parity tests" ; timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -15 | tee gpurun_out/${TAG}_parity.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
@@ -25,6 +25,7 @@ for f in glob.glob("/tmp/pmc_${TAG}_*/**/*counter_collection.csv", recursive=Tru
         k = r.get("Kernel_Name", "")
         if "clipamd" not in k: continue
         k = k.replace("void clipamd::(anonymous namespace)::", "").split("(")[0].replace(" ", "")
+        if k.startswith("_ZN7clipamd"): k = k.split("I")[0].replace("_ZN7clipamd12_GLOBAL__N_1", "")[2:] if False else k
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 out = {}
 for k in acc:
@@ -32,6 +33,11 @@ for k in acc:
     # rocprofv3 units: KB per dispatch; gfx950 correction (MI355X_MICROARCH.md): FETCH_SIZE reads 1/2 of a wide coalesced stream -> x2
     out[k] = {"fetch_kb_raw": fs, "write_kb_raw": ws, "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0, "launches": cnt[(k, "FETCH_SIZE")]}
     print("%-60s FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  -> HBM bytes/launch (fetch x2) %.3e  [%d launches]" % (k[:60], fs, ws, out[k]["hbm_bytes_per_launch"], cnt[(k, "FETCH_SIZE")]))
+import sys
+sys.path.insert(0, ".")
+import bench
+out["_kernel_src_sha16"] = bench.kernel_source_sha16()      # bench.py reports traffic only while the kernel sources are these
+out["_config"] = "b32_q4_0_b256"
 json.dump(out, open("gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
 print("-- MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs; 16 cycles per v_mfma_f32_16x16x32_f16; GRBM_GUI_ACTIVE = GPU-active cycles of the dispatch)")
 for k in acc:
