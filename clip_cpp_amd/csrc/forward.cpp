@@ -72,7 +72,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
         launch_gemm(p, epi, 0, ctx->stream);
         return;
     }
-    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad);
+    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
     const bool panel = gemm_tile_uses_panel(tile) && (p.W.wtype == W_F16 || p.w16_pre);
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double wb = panel ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);   // the 8-wave kernel reads the fp16 panel of W
@@ -109,11 +109,11 @@ LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows) {
     int nj = 0;
     size_t need = 0;
     for (int i = 0; i < 4; i++)
-        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad))) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
+        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true))) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
     if (!need || !ensure_panel(ctx, need)) return lp;
     size_t off = 0;
     for (int i = 0; i < 4; i++)
-        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad))) {
+        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true))) {
             jw[nj] = ws[i];
             jo[nj] = ctx->w16_panel + off;
             *slot[i] = jo[nj];

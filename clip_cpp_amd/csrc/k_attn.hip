@@ -183,7 +183,9 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
 // NT  = number of 16-key tiles (>= ceil(max_len/16)); DKS = 32-wide k-steps over the head dim (dh <= 32*DKS);
 // DT = dh/16 output tiles.
 template <int NT, int DKS, int DT>
-__global__ void __launch_bounds__(256, (NT > 18 ? 1 : 2)) attn_kernel(const AttnParams p) {
+// occupancy: short sequences (T <= 80: ViT-B/32 images, every text) are latency-bound — stage, one barrier, a handful of MFMAs — so 4
+// workgroups per CU (<= 128 VGPRs) instead of 2 hide twice the memory latency; long ones need the registers
+__global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_kernel(const AttnParams p) {
     constexpr int DKP = DKS * 32;
     // Long sequences (NT > 18: 336-px models, T = 577) only fit the 160 KB LDS without the row padding: K rows are then
     // exactly 128 B with the 16-byte chunks XOR-swizzled by (key & 7) instead (same conflict-free ds_read_b128 pattern

@@ -390,7 +390,7 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
 // one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
-int pick_tile(int M, int N, int Kpad) {
+int pick_tile(int M, int N, int Kpad, bool quantised) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
     if (wgs(128, 128) < 100) return wgs(64, 128) >= 256 ? 64128 : 64064;
@@ -401,7 +401,9 @@ int pick_tile(int M, int N, int Kpad) {
         const int t8 = wgs(160, 256);
         const float rounds = (float)t8 / 256.f;
         const float eff = rounds / ceilf(rounds);          // fraction of the last round's CUs that have work
-        if (t8 >= 200 && eff >= 0.75f && (Kpad >= 2048 || M >= 32768)) return 160256;
+        // block-quantised weights additionally pay the panel dequantisation (a ~7 us launch per layer at ViT-B/32 size: more than
+        // the 8-wave kernel gains there, r02h), so they take this path only where a layer is milliseconds long
+        if (t8 >= 200 && eff >= 0.75f && (M >= 32768 || (Kpad >= 2048 && !quantised))) return 160256;
     }
     int best = 128128;
     float best_cost = 0.f;
@@ -433,7 +435,7 @@ void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
-int gemm_tile_for(int M, int N, int Kpad) { return pick_tile(M, N, Kpad); }
+int gemm_tile_for(int M, int N, int Kpad, bool quantised) { return pick_tile(M, N, Kpad, quantised); }
 
 // Split-K factor for a BM = 64 tile grid (small-M problems: batch 1 / 32, single texts), fitted with
 // scripts/gemm_bench.py (profiles/r01_gemm_splitk.txt): a K-step costs ~0.5 us of serial latency, the fix-up ~3 us, so
@@ -453,7 +455,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
     const bool heuristic = (tile == 0);
     int ksplit = tile / 1000000;        // explicit: ksplit * 1000000 + BM * 1000 + BN  (no prefix = no split)
     tile %= 1000000;
-    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad);
+    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
     if (gemm_tile_uses_panel(tile)) {
         // 8-wave large-M kernel: fp16 x fp16 from a row-major panel of W; block-quantised weights are dequantised into it first
         // (unless the caller already did, per layer)

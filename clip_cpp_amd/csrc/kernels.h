@@ -86,7 +86,7 @@ struct GemmParams {
 // tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64;
 // BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
-int gemm_tile_for(int M, int N, int Kpad);   // the tile (BM*1000+BN) the heuristic picks for this shape
+int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
 inline bool gemm_tile_uses_panel(int tile) { return tile % 1000 == 256; }   // the shape runs on the 8-wave kernel (fp16 W panel)
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
