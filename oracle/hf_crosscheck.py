@@ -46,7 +46,10 @@ def weights_checksum(master):
     return h.hexdigest()
 
 
-def run(config="tiny", seed=1234, B=3, out_name=None):
+def run(config="tiny", seed=1234, B=3, out_name=None, act="quick_gelu", f16_weights=False):
+    """act: HF hidden_act of both towers ("gelu" = exact erf GELU: bounds the gap to ggml's tanh form, which the reference uses
+    whenever clip.use_gelu is set, clip.cpp:1410-1414); f16_weights: give HF the weights as an f16 GGUF stores them (2-D "*.weight"
+    tensors and the conv kernel rounded to fp16) so that the oracle can be run on the f16 FILE in ggml-faithful mode."""
     import torch
     from transformers import CLIPConfig, CLIPModel
 
@@ -55,11 +58,11 @@ def run(config="tiny", seed=1234, B=3, out_name=None):
     hf_cfg = CLIPConfig(
         text_config=dict(vocab_size=fixtures.N_VOCAB, hidden_size=t["h"], intermediate_size=t["ff"],
                          num_hidden_layers=t["L"], num_attention_heads=t["nh"], max_position_embeddings=t["npos"],
-                         hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=t["proj"],
+                         hidden_act=act, layer_norm_eps=1e-5, projection_dim=t["proj"],
                          bos_token_id=49406, eos_token_id=49407, pad_token_id=1),
         vision_config=dict(hidden_size=v["h"], intermediate_size=v["ff"], num_hidden_layers=v["L"],
                            num_attention_heads=v["nh"], image_size=v["S"], patch_size=v["P"],
-                           hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=v["proj"]),
+                           hidden_act=act, layer_norm_eps=1e-5, projection_dim=v["proj"]),
         projection_dim=v["proj"])
     model = CLIPModel(hf_cfg).eval().float()
     tmp = os.path.join("/tmp", "hfx_%s_%d.gguf" % (config, seed))
@@ -73,8 +76,8 @@ def run(config="tiny", seed=1234, B=3, out_name=None):
         w = master[g]
         used.add(g)
         assert tuple(sd[name].shape) == tuple(w.shape), (name, g, sd[name].shape, w.shape)
-        if g == "v.patch_embd.weight":
-            w = w.astype(np.float16).astype(np.float32)  # the GGUF stores the conv kernel in f16
+        if g == "v.patch_embd.weight" or (f16_weights and w.ndim == 2 and g.endswith("weight")):
+            w = w.astype(np.float16).astype(np.float32)  # the GGUF stores the conv kernel (and, in f16 files, every 2-D weight) in f16
         sd[name] = torch.from_numpy(w.copy())
     assert used == set(master), set(master) - used
     model.load_state_dict(sd)
@@ -90,7 +93,7 @@ def run(config="tiny", seed=1234, B=3, out_name=None):
             tout = model.text_model(input_ids=torch.from_numpy(ids.astype(np.int64))[None])
             txt_emb.append(model.text_projection(tout.pooler_output)[0].numpy())
     out = dict(images=imgs, image_embeds=img_emb, checksum=np.array(weights_checksum(master)),
-               config=np.array(config), seed=np.array(seed))
+               config=np.array(config), seed=np.array(seed), act=np.array(act), f16_weights=np.array(f16_weights))
     for i, (ids, e) in enumerate(zip(texts, txt_emb)):
         out["ids_%d" % i] = ids
         out["text_embeds_%d" % i] = e
@@ -104,3 +107,5 @@ def run(config="tiny", seed=1234, B=3, out_name=None):
 if __name__ == "__main__":
     for c in (sys.argv[1:] or ["tiny", "tiny14"]):
         print("wrote", run(c))
+    print("wrote", run("tiny", out_name="hf_tiny_erf_gelu.npz", act="gelu"))            # exact-GELU network (bounds ggml's tanh GELU)
+    print("wrote", run("tiny14", out_name="hf_tiny14_f16w.npz", f16_weights=True))      # weights as an f16 file stores them
