@@ -334,11 +334,11 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);   // big batches are GPU-bound: no graph needed
     clip_ctx::GraphEntry * e = nullptr;
     for (auto & g : ctx->vgraphs)
-        if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize) { e = &g; break; }
+        if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize && g.in_f16 == ctx->input_f16) { e = &g; break; }
     if (e && e->exec) return hipGraphLaunch(e->exec, ctx->stream) == hipSuccess;
     if (!e) {   // first sighting: run eagerly (allocates the workspace, sets kernel attributes)
         if (ctx->vgraphs.size() >= 16) drop_graphs(ctx);
-        ctx->vgraphs.push_back({B, d_imgs, d_out, normalize, 1, nullptr, nullptr});
+        ctx->vgraphs.push_back({B, d_imgs, d_out, normalize, ctx->input_f16, 1, nullptr, nullptr});
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
     }
     // second sighting: capture
@@ -406,11 +406,12 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
         Carver c(ctx->ws.base);
         carve(c, x, xn, qkv, att, mid, col, pooled, emb);
 
-        const float * imgs = d_imgs + (size_t)b0 * S * S * 3;
+        // (host-pointer path: the staging buffer holds fp16 pixels, converted while packing — host_pipeline.cpp)
+        const void * imgs = ctx->input_f16 ? (const void *)((const half_t *)d_imgs + (size_t)b0 * S * S * 3) : (const void *)(d_imgs + (size_t)b0 * S * S * 3);
         // patch embedding = im2col + GEMM (ggml_conv_2d, clip.cpp:1309-1312); epilogue scatters to token rows + pos
         {
-            ProfScope ps(ctx, "im2col", Bc * Np, V.patch.Kpad, 0, 0, (double)Bc * S * S * 3 * 4 + (double)Bc * Np * V.patch.Kpad * 2);
-            launch_im2col(imgs, col, Bc, S, P, V.patch.Kpad, s);
+            ProfScope ps(ctx, "im2col", Bc * Np, V.patch.Kpad, 0, 0, (double)Bc * S * S * 3 * (ctx->input_f16 ? 2 : 4) + (double)Bc * Np * V.patch.Kpad * 2);
+            launch_im2col(imgs, ctx->input_f16, col, Bc, S, P, V.patch.Kpad, s);
         }
         GemmParams pp;
         pp.A = col; pp.lda = V.patch.Kpad; pp.M = Bc * Np; pp.W = V.patch; pp.out = x; pp.ldc = h;

@@ -88,7 +88,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float * __restrict
 // im2col (fp16) for the stride-P, no-padding patch convolution: col[(b,oy,ox)][(c,ky,kx)] =
 // fp16(img[b][oy*P+ky][ox*P+kx][c]); two k's per thread, padded columns are zero.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) im2col_kernel(const float * __restrict__ imgs, half_t * __restrict__ col, int B, int S,
+// IT = float (preprocessed images as the API hands them over) or half_t (the host-pointer path converts to fp16 while packing its
+// pinned buffer — the same round-to-nearest-even this kernel applies, so the column matrix is bit-identical — and ships half the bytes)
+template <typename IT>
+__global__ void __launch_bounds__(256) im2col_kernel(const IT * __restrict__ imgs, half_t * __restrict__ col, int B, int S,
                                                      int P, int Kpad, long total2) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total2) return;
@@ -98,27 +101,28 @@ __global__ void __launch_bounds__(256) im2col_kernel(const float * __restrict__ 
     const int G = S / P, Np = G * G, K = 3 * P * P;
     const int b = (int)(m / Np), pp = (int)(m % Np);
     const int oy = pp / G, ox = pp % G;
-    float v[2];
+    _Float16 v[2];
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const int k = k0 + e;
-        float val = 0.f;
+        _Float16 val = (_Float16)0.f;
         if (k < K) {
             const int c = k / (P * P), rem = k % (P * P);
             const int ky = rem / P, kx = rem % P;
-            val = imgs[(size_t)b * S * S * 3 + 3 * ((size_t)(oy * P + ky) * S + (ox * P + kx)) + c];
+            val = (_Float16)imgs[(size_t)b * S * S * 3 + 3 * ((size_t)(oy * P + ky) * S + (ox * P + kx)) + c];
         }
         v[e] = val;
     }
-    const h2 o = (h2){(_Float16)v[0], (_Float16)v[1]};
+    const h2 o = (h2){v[0], v[1]};
     *(uint32_t *)(col + (size_t)m * Kpad + k0) = __builtin_bit_cast(uint32_t, o);
 }
 
 
-// Coalesced form for even P: one thread per (patch, ky, pixel pair).  It reads 6 consecutive floats of the interleaved
+// Coalesced form for even P: one thread per (patch, ky, pixel pair).  It reads 6 consecutive elements of the interleaved
 // image row (RGB RGB) and writes one half2 into each of the three channel planes of the patch row, so a wave reads
-// 1.5 KB contiguous and writes three 256-byte runs (the scalar kernel above strides the reads by 12 bytes).
-__global__ void __launch_bounds__(256) im2col_rows_kernel(const float * __restrict__ imgs, half_t * __restrict__ col, int S, int P,
+// 1.5 KB (0.75 KB for fp16 input) contiguous and writes three 256-byte runs (the scalar kernel above strides the reads by 12 bytes).
+template <typename IT>
+__global__ void __launch_bounds__(256) im2col_rows_kernel(const IT * __restrict__ imgs, half_t * __restrict__ col, int S, int P,
                                                           int Kpad, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -130,10 +134,16 @@ __global__ void __launch_bounds__(256) im2col_rows_kernel(const float * __restri
     const int G = S / P, Np = G * G;
     const int b = (int)(m / Np), pp = (int)(m % Np);
     const int oy = pp / G, ox = pp % G;
-    const float * src = imgs + (size_t)b * S * S * 3 + 3 * ((size_t)(oy * P + ky) * S + (ox * P + 2 * xp));
-    const float2 a = *(const float2 *)(src), c = *(const float2 *)(src + 2), e = *(const float2 *)(src + 4);   // r0 g0 | b0 r1 | g1 b1
+    const IT * src = imgs + (size_t)b * S * S * 3 + 3 * ((size_t)(oy * P + ky) * S + (ox * P + 2 * xp));
+    h2 rr, gg, bb;
+    if constexpr (sizeof(IT) == 4) {
+        const float2 a = *(const float2 *)(src), c = *(const float2 *)(src + 2), e = *(const float2 *)(src + 4);   // r0 g0 | b0 r1 | g1 b1
+        rr = (h2){(_Float16)a.x, (_Float16)c.y}; gg = (h2){(_Float16)a.y, (_Float16)e.x}; bb = (h2){(_Float16)c.x, (_Float16)e.y};
+    } else {
+        const h2 a = *(const h2 *)(src), c = *(const h2 *)(src + 2), e = *(const h2 *)(src + 4);
+        rr = (h2){a[0], c[1]}; gg = (h2){a[1], e[0]}; bb = (h2){c[0], e[1]};
+    }
     half_t * dst = col + (size_t)m * Kpad + ky * P + 2 * xp;
-    const h2 rr = (h2){(_Float16)a.x, (_Float16)c.y}, gg = (h2){(_Float16)a.y, (_Float16)e.x}, bb = (h2){(_Float16)c.x, (_Float16)e.y};
     *(uint32_t *)(dst) = __builtin_bit_cast(uint32_t, rr);
     *(uint32_t *)(dst + P * P) = __builtin_bit_cast(uint32_t, gg);
     *(uint32_t *)(dst + 2 * P * P) = __builtin_bit_cast(uint32_t, bb);
@@ -261,17 +271,22 @@ void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_
 #undef CLIPAMD_LN
 }
 
-void launch_im2col(const float * imgs, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream) {
+template <typename IT>
+static void launch_im2col_t(const IT * imgs, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream) {
     const int G = S / P;
     const long total2 = (long)B * G * G * (Kpad / 2);
     if (total2 <= 0) return;
-    if (P % 2 == 0 && Kpad == 3 * P * P && S % 2 == 0) {   // no K padding to zero-fill, 8-byte aligned pixel pairs
+    if (P % 2 == 0 && Kpad == 3 * P * P && S % 2 == 0) {   // no K padding to zero-fill, aligned pixel pairs
         const long total = (long)B * G * G * P * (P / 2);
-        hipLaunchKernelGGL(im2col_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, imgs, col, S, P, Kpad, total);
+        hipLaunchKernelGGL(im2col_rows_kernel<IT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, imgs, col, S, P, Kpad, total);
         return;
     }
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, imgs, col, B, S, P, Kpad,
-                       total2);
+    hipLaunchKernelGGL(im2col_kernel<IT>, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, imgs, col, B, S, P, Kpad, total2);
+}
+
+void launch_im2col(const void * imgs, bool imgs_f16, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream) {
+    if (imgs_f16) launch_im2col_t<half_t>((const half_t *)imgs, col, B, S, P, Kpad, stream);
+    else launch_im2col_t<float>((const float *)imgs, col, B, S, P, Kpad, stream);
 }
 
 void launch_cls_rows(float * x, const float * class_embd, const float * pos, int B, int T, int h, hipStream_t stream) {

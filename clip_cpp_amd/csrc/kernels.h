@@ -137,8 +137,8 @@ bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform,
                       int h, int n_head, bool causal, hipStream_t stream);
 
 // im2col for the stride-P patch convolution (reference clip.cpp:1309; ggml conv_2d im2col, fp16):
-// imgs [B][S][S][3] f32 interleaved -> col [B*Np][Kpad] fp16, k = (c*P + ky)*P + kx, zero padded to Kpad.
-void launch_im2col(const float * imgs, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream);
+// imgs [B][S][S][3] interleaved, f32 or (imgs_f16) already rounded to fp16 -> col [B*Np][Kpad] fp16, k = (c*P + ky)*P + kx, zero padded.
+void launch_im2col(const void * imgs, bool imgs_f16, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream);
 
 // x[b*T + 0][:] = class_embd + pos[0]   (reference clip.cpp:1315-1331, class-token row)
 void launch_cls_rows(float * x, const float * class_embd, const float * pos, int B, int T, int h, hipStream_t stream);

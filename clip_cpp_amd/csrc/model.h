@@ -107,6 +107,7 @@ struct clip_ctx {
     size_t io_in_bytes = 0;
     void * io_out = nullptr;
     size_t io_out_bytes = 0;
+    bool input_f16 = false;          // the vision forward's input pointer holds fp16 pixels (set by the host pipeline around its calls)
     clipamd::HostPipe pipe;          // pinned double-buffered staging of clip_image_batch_encode (host_pipeline.cpp)
     clipamd::MetaRing meta;          // pinned ring for the text tower's per-call offsets
     void * multi = nullptr;          // clipamd::MultiCtx* when loaded with clip_amd_model_load_multi (replicas on the other devices)
@@ -133,7 +134,7 @@ struct clip_ctx {
 
     // hipGraph cache for the vision forward (launch-bound at small batch: ~90 launches per pass).  A pass is captured the
     // second time the same (batch, input pointer, output pointer, normalize) signature is seen and replayed afterwards.
-    struct GraphEntry { int B; const void * in; void * out; bool norm; int seen; hipGraph_t graph; hipGraphExec_t exec; };
+    struct GraphEntry { int B; const void * in; void * out; bool norm; bool in_f16; int seen; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<GraphEntry> vgraphs;
     // ... and for the text forward at small token counts (single texts, short label lists): keyed on (texts, token rows,
     // attention key-tile bucket, pointers); the per-call sequence offsets live in device memory and are uploaded before the replay
