@@ -469,6 +469,10 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
+            if (tile % 1000 == 257) {
+                if (launch_gemm8_streamk(p, epilogue, stream)) return;
+                tile = 160256;
+            }
             launch_gemm8(p, epilogue, tile / 32000, stream);
             return;
         }

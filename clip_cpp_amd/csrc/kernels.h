@@ -87,10 +87,11 @@ struct GemmParams {
 // BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
 int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
-inline bool gemm_tile_uses_panel(int tile) { return tile % 1000 == 256; }   // the shape runs on the 8-wave kernel (fp16 W panel)
+inline bool gemm_tile_uses_panel(int tile) { return tile % 1000 == 256 || tile % 1000 == 257; }   // BN code 257: stream-K form of the 256 x 256 tile   // the shape runs on the 8-wave kernel (fp16 W panel)
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);
+bool launch_gemm8_streamk(const GemmParams & p, int epilogue, hipStream_t stream);   // false: workspace missing / too small
 // dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)
 struct DequantJobs { DevWeight W[4]; half_t * out[4]; int blk_end[4]; int n = 0; };
 void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, hipStream_t stream);

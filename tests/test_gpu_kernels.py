@@ -81,7 +81,7 @@ def test_gemm_all_weight_types_vs_dequant_reference(L, tname, shape):
     assert rel < (5e-4 if tname in ("f16", "f32") else 2e-2), rel
 
 
-@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128, 96256, 128256, 160256])
+@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128, 96256, 128256, 160256, 256256])
 @pytest.mark.parametrize("tname", ["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     """Every tile shape accumulates each output in the same k order -> identical bits; also exercises M/N edges."""
@@ -296,7 +296,7 @@ def test_gemm_patch_embedding_epilogue(L, B, G, h, P):
     assert np.all(np.abs(y3[:, 1:, :] - want) <= bound.reshape(B, Np, h))
 
 
-@pytest.mark.parametrize("tile", [96256, 128256, 160256])
+@pytest.mark.parametrize("tile", [96256, 128256, 160256, 256256])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 448, 1024])
 @pytest.mark.parametrize("tname,epi", [("f16", 0), ("q4_0", 4), ("q5_1", 1), ("q8_0", 2)])
 def test_gemm8_ring_lengths_and_epilogues_match_the_4_wave_kernel_bitwise(L, tile, K, tname, epi):
@@ -327,6 +327,28 @@ def test_gemm8_many_tiles_race_screen(L):
     base = run_gemm(L, 1, raw, N, K, X, epi=0, tile=128128)
     for _ in range(6):
         assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=160256), base)
+        assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=256256), base)     # 2-deep ring form
+
+
+@pytest.mark.parametrize("M,N,K", [(333, 576, 192), (200, 256, 3072), (4000, 1024, 768), (2051, 768, 64), (700, 300, 1024), (12800, 768, 3072)])
+@pytest.mark.parametrize("tname,epi", [("f16", 0), ("q4_0", 4), ("q5_1", 1), ("q8_0", 3)])
+def test_gemm8_stream_k_is_deterministic_and_matches_unsplit(L, M, N, K, tname, epi):
+    """Stream-K form of the 256 x 256 tile (k_gemm8.hip, gemm8sk_kernel; tile code 256257): the (tile, K-tile) units are cut into one
+    equal range per CU, split tiles are finished by the owner of their k = 0 part adding the parked partial sums in part order.
+    Same bits run to run; equal to the unsplit kernel up to one fp32 re-association per split tile.  Shapes: fewer units than CUs,
+    one tile spread over many CUs (200 x 256, K = 3072), ranges of several whole tiles, M / N edges, every epilogue family."""
+    rng = np.random.default_rng(M + K)
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K) * 3)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + 128128)
+    y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=256257)
+    assert np.all(np.isfinite(y))
+    assert np.abs(y - base).max() <= 2e-3 * max(1.0, np.abs(base).max()), np.abs(y - base).max()
+    for _ in range(3):
+        assert np.array_equal(run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=256257), y)
 
 
 def run_skinny(L, tid, raw, N, K, X, bias=None, resid=None, ln=None, epi=0, qcols=0, qscale=1.0, stats=None):
