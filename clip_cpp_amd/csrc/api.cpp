@@ -654,14 +654,42 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
-    for (int i = 0; i < 3; i++) launch_gemm(p, epilogue, tile, nullptr);
+    // GEMM_ROTATE=R: cycle through R separate copies of the weight (and of its panel), as the layers of a tower do — the
+    // default re-multiplies one weight, which stays in L2 / Infinity Cache
+    int rot = 1;
+    { const char * e = getenv("GEMM_ROTATE"); if (e) rot = atoi(e); if (rot < 1) rot = 1; if (rot > 64) rot = 64; }
+    std::vector<DevWeight> Ws(1, p.W);
+    std::vector<const half_t *> pans(1, p.w16_pre);
+    std::vector<void *> owned;
+    for (int r = 1; r < rot; r++) {
+        DevWeight Wr;
+        void * base = nullptr;
+        if (!repack_for_test(type, raw.data(), N, K, Wr, &base)) break;
+        owned.push_back(base);
+        const half_t * pr = nullptr;
+        if (pre && Wr.wtype != W_F16) {
+            void * pp = nullptr;
+            if (hipMalloc(&pp, (size_t)Wr.Npad * Wr.Kpad * 2) != hipSuccess) break;
+            owned.push_back(pp);
+            const DevWeight * w = &Wr;
+            half_t * o = (half_t *)pp;
+            launch_dequant(&w, &o, 1, nullptr);
+            pr = (const half_t *)pp;
+        }
+        Ws.push_back(Wr);
+        pans.push_back(pr);
+    }
+    rot = (int)Ws.size();
+    auto go = [&](int i) { p.W = Ws[i % rot]; if (pre) p.w16_pre = pans[i % rot]; launch_gemm(p, epilogue, tile, nullptr); };
+    for (int i = 0; i < 3; i++) go(i);
     (void)hipEventRecord(a, nullptr);
-    for (int i = 0; i < iters; i++) launch_gemm(p, epilogue, tile, nullptr);
+    for (int i = 0; i < iters; i++) go(i);
     (void)hipEventRecord(b, nullptr);
     float ms = -1.f;
     if (hipEventSynchronize(b) == hipSuccess && hipGetLastError() == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    for (void * o : owned) (void)hipFree(o);
     if (getenv("CLIPAMD_G8_STAMPS")) {   // tuning builds (-DCLIPAMD_G8_TIMING): dump the per-workgroup phase stamps of the last launch
         const int nwg = 4096;
         std::vector<unsigned long long> st((size_t)nwg * 8);

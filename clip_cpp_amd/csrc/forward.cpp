@@ -72,15 +72,16 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
         launch_gemm(p, epi, 0, ctx->stream);
         return;
     }
-    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
-    const bool panel = gemm_tile_uses_panel(tile) && (p.W.wtype == W_F16 || p.w16_pre);
+    const int wt = p.w16_pre ? (int)W_F16 : p.W.wtype;       // a dequantised panel is multiplied as an f16 weight (launch_gemm)
+    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, wt != W_F16);
+    const bool panel = gemm_tile_uses_panel(tile) && wt == W_F16;
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
-    const double wb = panel ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);   // the 8-wave kernel reads the fp16 panel of W
+    const double wb = wt == W_F16 ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);
     const double by = wb + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4);   // fused residual: read + write
     // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
     if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
-    else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", p.W.wtype, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
+    else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", wt, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
     ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
     launch_gemm(p, epi, 0, ctx->stream);
 }

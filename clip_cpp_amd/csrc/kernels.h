@@ -87,7 +87,9 @@ struct GemmParams {
 // BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
 int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
-inline bool gemm_tile_uses_panel(int tile) { return tile % 1000 == 256 || tile % 1000 == 257; }   // BN code 257: stream-K form of the 256 x 256 tile   // the shape runs on the 8-wave kernel (fp16 W panel)
+// the shape runs on the 8-wave kernel (fp16 W panel).  BN codes: 256 plain, 257 stream-K form of the 256 x 256 tile, 258 the
+// 256 x 256 tile on the rows that fill whole rounds + a second launch for the rest
+inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return bn >= 256 && bn <= 258; }
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);

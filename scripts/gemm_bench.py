@@ -22,6 +22,7 @@ SHAPES = [  # (name, M, N, K, epi)
     ("l14.qkv", 65792, 3072, 1024, 1), ("l14.out", 65792, 1024, 1024, 4),
     ("l14.b32.qkv", 8224, 3072, 1024, 1), ("l14.b32.out", 8224, 1024, 1024, 4), ("l14.b32.up", 8224, 4096, 1024, 3), ("l14.b32.down", 8224, 1024, 4096, 4),
     ("b64.qkv", 3200, 2304, 768, 1), ("b64.out", 3200, 768, 768, 4), ("b64.up", 3200, 3072, 768, 3), ("b64.down", 3200, 768, 3072, 4),
+    ("b1024.qkv", 51200, 2304, 768, 1), ("b1024.out", 51200, 768, 768, 4), ("b1024.up", 51200, 3072, 768, 3), ("b1024.down", 51200, 768, 3072, 4),
     ("b128.qkv", 6400, 2304, 768, 1), ("b128.out", 6400, 768, 768, 4), ("b128.up", 6400, 3072, 768, 3), ("b128.down", 6400, 768, 3072, 4),
 ]
 tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
@@ -30,6 +31,7 @@ if 'ksweep' in sys.argv[1:]:
 types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
 only = [a for a in sys.argv[1:] if "." in a]
 debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]
+ITERS = int(os.environ.get("GEMM_ITERS", "20"))   # long runs (thousands) show the sustained, power-limited rate
 PRE = (1 << 16) if "pre" in sys.argv[1:] else 0   # 8-wave kernel: time the GEMM alone on an already dequantised fp16 panel (per-layer form)
 if "blas" in sys.argv[1:]:
     # yardstick: the vendor library (hipBLASLt / rocBLAS through torch) on the same shapes, plain f16 x f16 -> f16, no epilogue
@@ -56,6 +58,6 @@ for tname in types:
         row = []
         for tile in tiles:
             for dbg in debug:
-                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8) | PRE, tile, 20)
+                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8) | PRE, tile, ITERS)
                 row.append("%7d%s: %8.1f us %7.1f TF" % (tile, ("/d%d" % dbg) if dbg else "", us, 2.0 * M * N * K / us / 1e6 if us > 0 else -1))
         print("%-5s %-14s M=%6d N=%5d K=%5d | %s" % (tname, name, M, N, K, " | ".join(row)), flush=True)

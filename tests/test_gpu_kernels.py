@@ -330,6 +330,22 @@ def test_gemm8_many_tiles_race_screen(L):
         assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=256256), base)     # 2-deep ring form
 
 
+@pytest.mark.parametrize("tname,epi", [("f16", 1), ("q4_0", 4), ("q8_0", 3), ("q5_0", 0)])
+def test_gemm8_whole_rounds_split_is_bitwise_identical(L, tname, epi):
+    """Tile code 256258: the tile rows that fill whole rounds of 256 workgroups go to the 256 x 256 kernel, the remaining rows to a
+    second launch with the heuristic's tile.  Row-local epilogues, no K split: the same bits as one launch of any tile."""
+    rng = np.random.default_rng(11)
+    M, N, K = 5000, 3584, 128            # 20 x 14 = 280 tiles: 18 tile rows (4608 rows) in the first launch, 392 rows in the second
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K) * 3)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=128128)
+    y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=256258)
+    assert np.array_equal(base, y), np.abs(base - y).max()
+
+
 @pytest.mark.parametrize("M,N,K", [(333, 576, 192), (200, 256, 3072), (4000, 1024, 768), (2051, 768, 64), (700, 300, 1024), (12800, 768, 3072)])
 @pytest.mark.parametrize("tname,epi", [("f16", 0), ("q4_0", 4), ("q5_1", 1), ("q8_0", 3)])
 def test_gemm8_stream_k_is_deterministic_and_matches_unsplit(L, M, N, K, tname, epi):
