@@ -80,7 +80,8 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
     const double by = wb + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4);   // fused residual: read + write
     // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
-    if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
+    if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
+    else if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
     else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", wt, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
     ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
     launch_gemm(p, epi, 0, ctx->stream);

@@ -131,27 +131,44 @@ __device__ __forceinline__ float gelu_quick(float x) { return x * __builtin_amdg
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp) {
     const int N = p.W.N;
+    // Everything the K loop requested has landed.  Said with the BUILTIN so that hipcc's waitcnt pass sees it: an LDS-DMA request
+    // (a FLAT-encoded instruction touching two address spaces) leaves that pass in its "pending flat" state, in which every later
+    // wait is vmcnt(0) / lgkmcnt(0) — in an epilogue that means each group of loads also waits for all earlier STORES to be acked.
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    // all bias vectors of the wave's columns in one batch (one memory round trip instead of TN dependent ones)
+    f4 biasv[TN];
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        int n = nbase + a * 16 + fgrp * 4;
+        n = n < N ? n : 0;                             // (clamped: columns past N are never stored)
+        biasv[a] = (EPI != EPI_PATCH_F32 && p.bias) ? *(const f4 *)(p.bias + n) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (EPI == EPI_RESID_F32) {
         // Residual rows are fetched TM at a time with clamped (always valid) row indices, so the loads of one column strip are all
-        // in flight together; written as load-add-store under an `m < M` branch each fragment waited out its own memory round trip
-        // (TN x TM dependent round trips per tile: 15-44 % of the ViT-B/32 residual GEMMs).
-#pragma unroll
-        for (int a = 0; a < TN; a++) {
-            const int n = nbase + a * 16 + fgrp * 4;
-            if (n >= N) continue;
-            f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bias = *(const f4 *)(p.bias + n);
-            f4 r[TM];
+        // in flight together, and one strip AHEAD: the loads of strip a+1 are issued before strip a is added and stored (written as
+        // load-add-store under an `m < M` branch each fragment waited out its own memory round trip: TN x TM dependent round trips
+        // per tile, 15-44 % of the ViT-B/32 residual GEMMs; one strip at a time still left TN exposed round trips).
+        f4 r[2][TM];
+        auto fetch = [&](int a, f4 (&dst)[TM]) {
+            int n = nbase + a * 16 + fgrp * 4;
+            n = n < N ? n : 0;
 #pragma unroll
             for (int b = 0; b < TM; b++) {
                 const int m = mbase + b * 16 + frow;
                 const int mc = m < p.M ? m : p.M - 1;
-                r[b] = *(const f4 *)(p.resid + (size_t)mc * p.ldc + n);
+                dst[b] = *(const f4 *)(p.resid + (size_t)mc * p.ldc + n);
             }
+        };
+        fetch(0, r[0]);
+#pragma unroll
+        for (int a = 0; a < TN; a++) {
+            if (a + 1 < TN) fetch(a + 1, r[(a + 1) & 1]);
+            const int n = nbase + a * 16 + fgrp * 4;
+            if (n >= N) continue;
 #pragma unroll
             for (int b = 0; b < TM; b++) {
                 const int m = mbase + b * 16 + frow;
-                if (m < p.M) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r[b] + (acc[a][b] + bias);
+                if (m < p.M) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r[a & 1][b] + (acc[a][b] + biasv[a]);
             }
         }
         return;
@@ -160,8 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
     for (int a = 0; a < TN; a++) {
         const int n = nbase + a * 16 + fgrp * 4;
         if (n >= N) continue;
-        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PATCH_F32 && p.bias) bias = *(const f4 *)(p.bias + n);
+        const f4 bias = biasv[a];
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             const int m = mbase + b * 16 + frow;
@@ -203,11 +219,14 @@ template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
                                                          half_t * stage, int lane) {
     constexpr int RS = 68;                                     // halfs per staged row (64 + 4 pad = 136 B)
+    __builtin_amdgcn_s_waitcnt(0x0070);                        // (see gemm_epilogue: lets hipcc count its waits again)
+    f4 biasv[TN];                                              // one batch of loads, not TN dependent round trips
+#pragma unroll
+    for (int a = 0; a < TN; a++) biasv[a] = p.bias ? *(const f4 *)(p.bias + nbase + a * 16 + fgrp * 4) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < TN; a++) {
         const int n = nbase + a * 16 + fgrp * 4;
-        f4 bias = (f4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *(const f4 *)(p.bias + n);
+        const f4 bias = biasv[a];
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             f4 v = acc[a][b] + bias;

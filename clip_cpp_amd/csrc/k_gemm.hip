@@ -37,7 +37,6 @@
 // The remaining step is a 256-wide register tile with a hand-scheduled (assembly) K loop.
 
 #include "gemm_common.h"
-#include <cstdlib>
 
 namespace clipamd {
 
@@ -398,8 +397,12 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
     // large M: the 8-wave 160 x 256 kernel (k_gemm8.hip), one workgroup per CU -> rounds of 256 tiles.  Its K loop is the faster
     // one (3-stage ring, ping-pong: ~69 % of the MFMA peak in the loop) but with one workgroup per CU nothing overlaps a tile's
     // prologue and epilogue, so it wins where the K loop dominates the tile: long K, or many rounds (profiles/r02_gemm8_*.txt)
-    static const bool no_gemm8 = [] { const char * e = getenv("CLIP_AMD_NO_GEMM8"); return e && e[0] == '1'; }();   // tuning switch
-    if (!no_gemm8) {
+    // the largest problems (ViT-L/14 at batch 256: 65792 rows; ViT-B/32 from batch ~700): 256 x 256 tiles, four waves of 128 x 128 with
+    // the accumulators in AGPRs (k_gemm4.hip), on the tile rows that fill whole rounds of 256 workgroups + a second launch for the rest.
+    // Sustained (200 launches, profiles/r02_gemm8_experiments.txt section 11): l14.qkv 447 us vs 468 (160 x 256) / 485 (160 x 128),
+    // l14.down 542 vs 579 / 607, l14.up 645 vs 652 / 705.
+    if (M >= 32768 && wgs(256, 256) >= 3 * 256) return 256260;
+    {
         const int t8 = wgs(160, 256);
         const float rounds = (float)t8 / 256.f;
         const float eff = rounds / ceilf(rounds);          // fraction of the last round's CUs that have work
@@ -464,14 +467,14 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         p.W.w16 = p.w16_pre;
     }
     if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
-    if (tile % 1000 == 258) {
+    if (tile % 1000 == 258 || tile % 1000 == 260) {
         // 256 x 256 tiles in whole rounds: one workgroup per CU means a launch costs ceil(tiles / 256) rounds, and ViT-L/14's
         // 65792 rows are 257 tile rows — one past a round boundary for every N.  The leading tile rows that fill whole rounds go to
         // the 256 x 256 kernel, the remaining rows to whatever the heuristic picks for that (much smaller) problem; the epilogues
         // are row-local, so the two launches write disjoint rows (not the patch epilogue: its rows map to (image, token)).
         const int tiles_n = (p.W.N + 255) / 256, tiles_m = (p.M + 255) / 256;
         const int mb = (int)(((long)tiles_m * tiles_n / 256) * 256 / tiles_n);     // tile rows inside the whole rounds
-        tile = 256256;
+        tile = tile % 1000 == 258 ? 256256 : 256259;
         if (epilogue != EPI_PATCH_F32 && mb > 0 && mb < tiles_m) {
             const int m1 = mb * 256;
             const bool f16_out = epilogue == EPI_F16 || epilogue == EPI_GELU_F16 || epilogue == EPI_QGELU_F16;
@@ -481,7 +484,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
             rest.A = p.A + (size_t)m1 * p.lda;
             rest.out = (char *)p.out + (size_t)m1 * p.ldc * (f16_out ? sizeof(half_t) : sizeof(float));
             if (p.resid) rest.resid = p.resid + (size_t)m1 * p.ldc;
-            launch_gemm(head, epilogue, 256256, stream);
+            launch_gemm(head, epilogue, tile, stream);
             launch_gemm(rest, epilogue, 0, stream);
             return;
         }
@@ -502,6 +505,10 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
             if (tile % 1000 == 257) {
                 if (launch_gemm8_streamk(p, epilogue, stream)) return;
                 tile = 160256;
+            }
+            if (tile % 1000 == 259) {
+                launch_gemm4(p, epilogue, stream);
+                return;
             }
             launch_gemm8(p, epilogue, tile / 32000, stream);
             return;

@@ -12,6 +12,7 @@ for wt in 0 1 2 3 4 5; do
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm.hip -o $V/k_gemm.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm8.hip -o $V/k_gemm8.hip.o &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm4.hip -o $V/k_gemm4.hip.o &
 wait
 OBJS=$(ls $B/*.o | grep -v 'k_gemm')
 hipcc --offload-arch=gfx950 -shared -fPIC -o clip_cpp_amd/variants/libclip_$NAME.so $OBJS $V/*.o -lz -lpthread -ldl

@@ -30,6 +30,17 @@ def run_gemm(L, tid, raw, N, K, X, bias=None, resid=None, epi=0, tile=0):
     return y
 
 
+def _diff_report(base, y):
+    """where two outputs that should be bit-identical differ (assertion message of the bitwise tile tests)."""
+    bad = np.argwhere(~((y == base) | (np.isnan(y) & np.isnan(base))))
+    if not len(bad):
+        return "identical"
+    r, c = bad[:, 0], bad[:, 1]
+    return "%d elements differ: rows %d..%d (16-row groups %s) cols %d..%d (16-col groups %s); first %s got %r want %r; nan %d" % (
+        len(bad), r.min(), r.max(), sorted(set((r // 16).tolist()))[:20], c.min(), c.max(), sorted(set((c // 16).tolist()))[:20],
+        bad[0].tolist(), float(y[tuple(bad[0])]), float(base[tuple(bad[0])]), int(np.isnan(y).sum()))
+
+
 def gelu_tanh(x):
     x = x.astype(np.float64)
     return 0.5 * x * (1 + np.tanh(0.7978845608028654 * x * (1 + 0.044715 * x * x)))
@@ -81,7 +92,7 @@ def test_gemm_all_weight_types_vs_dequant_reference(L, tname, shape):
     assert rel < (5e-4 if tname in ("f16", "f32") else 2e-2), rel
 
 
-@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128, 96256, 128256, 160256, 256256])
+@pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128, 96256, 128256, 160256, 256256, 256259])
 @pytest.mark.parametrize("tname", ["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     """Every tile shape accumulates each output in the same k order -> identical bits; also exercises M/N edges."""
@@ -92,7 +103,7 @@ def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     X = rng.standard_normal((M, K)).astype(np.float32)
     base = run_gemm(L, tid, raw, N, K, X, epi=0, tile=64064)
     y = run_gemm(L, tid, raw, N, K, X, epi=0, tile=tile)
-    assert np.array_equal(base, y)
+    assert np.array_equal(base, y), _diff_report(base, y)
 
 
 @pytest.mark.parametrize("ksplit,tile", [(2, 64064), (3, 64064), (5, 64128), (12, 64064)])
@@ -296,7 +307,7 @@ def test_gemm_patch_embedding_epilogue(L, B, G, h, P):
     assert np.all(np.abs(y3[:, 1:, :] - want) <= bound.reshape(B, Np, h))
 
 
-@pytest.mark.parametrize("tile", [96256, 128256, 160256, 256256])
+@pytest.mark.parametrize("tile", [96256, 128256, 160256, 256256, 256259])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 448, 1024])
 @pytest.mark.parametrize("tname,epi", [("f16", 0), ("q4_0", 4), ("q5_1", 1), ("q8_0", 2)])
 def test_gemm8_ring_lengths_and_epilogues_match_the_4_wave_kernel_bitwise(L, tile, K, tname, epi):
@@ -313,7 +324,7 @@ def test_gemm8_ring_lengths_and_epilogues_match_the_4_wave_kernel_bitwise(L, til
     base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + 64064)   # unsplit 64x64 tiles
     y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
     assert np.all(np.isfinite(y))
-    assert np.array_equal(base, y), np.abs(base - y).max()
+    assert np.array_equal(base, y), _diff_report(base, y)
     y2 = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
     assert np.array_equal(y, y2)
 
@@ -328,6 +339,7 @@ def test_gemm8_many_tiles_race_screen(L):
     for _ in range(6):
         assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=160256), base)
         assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=256256), base)     # 2-deep ring form
+        assert np.array_equal(run_gemm(L, 1, raw, N, K, X, epi=0, tile=256259), base)     # 4-wave 128 x 128 form (k_gemm4.hip)
 
 
 @pytest.mark.parametrize("tname,epi", [("f16", 1), ("q4_0", 4), ("q8_0", 3), ("q5_0", 0)])
@@ -342,8 +354,9 @@ def test_gemm8_whole_rounds_split_is_bitwise_identical(L, tname, epi):
     bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
     resid = rng.standard_normal((M, N)).astype(np.float32)
     base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=128128)
-    y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=256258)
-    assert np.array_equal(base, y), np.abs(base - y).max()
+    for tile in (256258, 256260):
+        y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
+        assert np.array_equal(base, y), (tile, np.abs(base - y).max())
 
 
 @pytest.mark.parametrize("M,N,K", [(333, 576, 192), (200, 256, 3072), (4000, 1024, 768), (2051, 768, 64), (700, 300, 1024), (12800, 768, 3072)])
