@@ -306,7 +306,7 @@ def main():
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None}
                        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:16]}
 
-    host_api = None
+    host_api = host_api_x4 = None
     if not args.no_host_api and rank == 0 and N == 1:
         # the drop-in boundary itself: clip_image_batch_encode from the caller's pageable float buffers (H2D + D2H inside the call)
         h_imgs = imgs.cpu().numpy()
@@ -317,6 +317,16 @@ def main():
         for _ in range(reps):
             clip.encode_images(h_imgs)
         host_api = round(batch * reps / (time.perf_counter() - t), 1)
+        # ... and with 4 x the batch per call: a call of several 256-image chunks overlaps pack + H2D of chunk c+1 with the forward of
+        # chunk c (host_pipeline.cpp), which one chunk per call cannot
+        host_big = np.concatenate([h_imgs] * 4, axis=0)
+        clip.encode_images(host_big)
+        reps4 = max(1, reps // 2)
+        t = time.perf_counter()
+        for _ in range(reps4):
+            clip.encode_images(host_big)
+        host_api_x4 = round(4 * batch * reps4 / (time.perf_counter() - t), 1)
+        del host_big
         del h_imgs
 
     cpu_baseline = None
@@ -370,6 +380,7 @@ def main():
                        "text_tokens_per_gpu": int(offsets[-1]), "parallelism": "dp%d" % N},
             "images_per_s_per_gpu": round(img_rate, 1), "texts_per_s_per_gpu": round(txt_rate, 1),
             "host_api_images_per_s": host_api,
+            "host_api_images_per_s_4x_batch_per_call": host_api_x4,
             "roofline": roofline, "whole_step_roofline": whole, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)",
         }

@@ -337,10 +337,13 @@ class Clip:
         """float32 [B,S,S,3] preprocessed images (host) -> float32 [B,proj] via clip_image_batch_encode."""
         imgs = np.ascontiguousarray(imgs, dtype=np.float32)
         B, S = imgs.shape[0], imgs.shape[1]
-        arr = (ClipImageF32 * B)()
-        for b in range(B):
-            arr[b] = ClipImageF32(S, imgs.shape[2], imgs[b].ctypes.data_as(C.POINTER(C.c_float)), imgs[b].size)
-        batch = ClipImageF32Batch(C.cast(arr, C.POINTER(ClipImageF32)), B)
+        # the clip_image_f32 array, filled without a Python loop (one ctypes object per image costs ~7 us: 1.8 ms per 256 images,
+        # a third of the call); layout = struct clip_image_f32 {int nx, ny; float * data; size_t size;} (clip.h:57-64)
+        rec = np.empty(B, dtype=np.dtype([("nx", np.int32), ("ny", np.int32), ("data", np.uint64), ("size", np.uint64)], align=True))
+        assert rec.dtype.itemsize == C.sizeof(ClipImageF32)
+        rec["nx"], rec["ny"], rec["size"] = S, imgs.shape[2], imgs[0].size if B else 0
+        rec["data"] = imgs.ctypes.data + np.arange(B, dtype=np.uint64) * np.uint64(imgs.strides[0] if B else 0)
+        batch = ClipImageF32Batch(C.cast(rec.ctypes.data, C.POINTER(ClipImageF32)), B)
         out = np.empty((B, self.vision_config["projection_dim"]), dtype=np.float32)
         if not lib().clip_image_batch_encode(self.ctx, n_threads or min(16, os.cpu_count() or 1), C.byref(batch), _fp(out), normalize):
             raise RuntimeError("clip_image_batch_encode failed (see stderr)")

@@ -3,10 +3,10 @@
 //
 // 1. encode_images_from_host: the caller's images are B separate pageable allocations of S*S*3 floats.  Copying them with one
 //    hipMemcpyAsync each lets the driver bounce every image through its own staging buffer on ONE thread (measured r01:
-//    20.6k img/s against 72k device-resident).  Here `n_threads` host threads pack sub-chunks of the batch into a pinned buffer;
-//    as soon as a sub-chunk is packed its single H2D copy is queued on a copy stream, and the vision tower runs on it on the
-//    compute stream as soon as that copy lands — pack(k+1) || H2D(k) || forward(k-1).  Two pinned / device buffer pairs
-//    alternate between chunks (<= 256 images), so packing of chunk c+1 overlaps the GPU work of chunk c.
+//    20.6k img/s against 72k device-resident).  Here `n_threads` host threads convert the images to fp16 into a pinned buffer; each
+//    32-image piece is copied (copy stream) as soon as it is packed, and the vision tower runs once per chunk of <= 256 images on
+//    the compute stream when the chunk's last piece has landed.  Two pinned / device buffer pairs alternate between chunks, so
+//    pack + copy of chunk c+1 overlap the forward of chunk c.
 //
 // 2. clip_amd_model_load_multi / multi_image_batch_encode: single process, one replica context + stream + host thread per
 //    device, contiguous shards of ceil(B/G) images (only its shard is copied to a device), identical kernels, then ONE
@@ -76,13 +76,25 @@ bool grow_device(void *& p, size_t & have, size_t want) {
 
 }  // namespace
 
-int host_pipeline_subchunk(int n) {
+// Two granularities.  COPY pieces (32 images, ~10 MB of fp16): a piece's H2D is queued the moment the packers have filled it, so the
+// copy engine trails the packers by one piece.  FORWARD groups: the vision tower runs once per group, after the group's last piece has
+// landed.  r02 first ran the tower per 128-image piece (pack || copy || forward), but the tower's per-image rate at 128 images is 58k/s
+// against 75k/s at 256 (profiles/r02_host_api.txt): the forwards, not the copies, were the critical path.  One forward per chunk of
+// <= 256 images overlaps only pack with copy inside a chunk — and chunk c+1's pack + copy with chunk c's forward; a call that is a
+// single chunk keeps two forwards of 128 so that the second half's pack + copy hide under the first forward.
+// Measured (profiles/r02_host_api.txt, ViT-B/32, 16 packer threads): 256 images per call: groups of 128 -> 44k img/s, one group of 256 ->
+// 41k (nothing overlaps the forward), 64 -> 35k; 1024 per call (4 chunks): one forward per chunk 60k img/s, groups of 128 55k.
+int host_pipeline_subchunk(int n, bool more_chunks) {
     static int forced = -1;
     if (forced < 0) { const char * e = getenv("CLIP_AMD_HOST_SUBCHUNK"); forced = e && atoi(e) > 0 ? atoi(e) : 0; }
-    if (forced) return forced;
-    // measured (profiles/r02_host_api.txt, ViT-B/32, 256 images per call): sub-chunks of 128 -> 34k img/s, 64 -> 30k, 256 (no overlap)
-    // -> 28k: the forward pass of a 64-image sub-chunk runs at half the per-image rate of a 256-image one, so finer overlap loses
-    return n < 192 ? n : 128;
+    if (forced) return forced < n ? forced : n;
+    return (more_chunks || n < 192) ? n : 128;
+}
+static int host_pipeline_copy_piece(int n) {
+    static int forced = -1;
+    if (forced < 0) { const char * e = getenv("CLIP_AMD_HOST_COPY_PIECE"); forced = e && atoi(e) > 0 ? atoi(e) : 0; }
+    const int cp = forced ? forced : 32;
+    return cp < n ? cp : n;
 }
 
 // n preprocessed images (host, S x S x 3 floats each, checked by the caller) -> d_out [n][proj] on ctx's device.
@@ -133,31 +145,36 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
             ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;
         }
         hp.used[buf] = true;
-        const int sc = host_pipeline_subchunk(bc);
-        const int n_sub = (bc + sc - 1) / sc;
-        std::vector<std::atomic<int>> packed(n_sub);
+        const int fg = host_pipeline_subchunk(bc, n_chunks > 1);   // images per forward
+        const int cp = host_pipeline_copy_piece(fg);        // images per H2D copy (pieces never straddle a forward group)
+        const int ppg = (fg + cp - 1) / cp;                 // pieces per (full) forward group
+        const int n_grp = (bc + fg - 1) / fg;
+        std::vector<std::atomic<int>> packed((size_t)n_grp * ppg);
         for (auto & a : packed) a.store(0, std::memory_order_relaxed);
         auto pack = [&](int t) {
-            for (int i = t; i < bc; i += P) {                 // image i of the chunk; sub-chunks fill in order
+            for (int i = t; i < bc; i += P) {                 // image i of the chunk; pieces fill in order
                 cvt_f16(imgs[b0 + i].data, pin + per * i, per);
-                packed[i / sc].fetch_add(1, std::memory_order_release);
+                packed[(size_t)(i / fg) * ppg + (i % fg) / cp].fetch_add(1, std::memory_order_release);
             }
         };
         std::vector<std::thread> pool;
         if (P > 1 && bc >= 8) for (int t = 1; t < P; t++) pool.emplace_back(pack, t);
         else { for (int t = 1; t < P; t++) pack(t); }
         pack(0);
-        for (int k = 0; k < n_sub && ok; k++) {
-            const int s0 = k * sc, sn = std::min(sc, bc - s0);
-            const auto tw0 = std::chrono::steady_clock::now();
-            while (packed[k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
+        for (int g = 0; g < n_grp && ok; g++) {
+            const int g0 = g * fg, gn = std::min(fg, bc - g0);
+            for (int k = 0; k * cp < gn && ok; k++) {
+                const int s0 = g0 + k * cp, sn = std::min(cp, g0 + gn - s0);
+                const auto tw0 = std::chrono::steady_clock::now();
+                while (packed[(size_t)g * ppg + k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
+                t_wait_pack += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+                ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
+            }
             const auto tw1 = std::chrono::steady_clock::now();
-            t_wait_pack += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
-            ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
             ok = ok && hipEventRecord(hp.ev_sub, hp.copy_stream) == hipSuccess;
             ok = ok && hipStreamWaitEvent(ctx->stream, hp.ev_sub, 0) == hipSuccess;
             ctx->input_f16 = true;
-            ok = ok && vision_forward_device(ctx, (const float *)(dev + per * s0), sn, d_out + (size_t)(b0 + s0) * proj, normalize);
+            ok = ok && vision_forward_device(ctx, (const float *)(dev + per * g0), gn, d_out + (size_t)(b0 + g0) * proj, normalize);
             ctx->input_f16 = false;
             t_enqueue += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
         }

@@ -1,9 +1,11 @@
 #!/bin/bash
+# host-pointer API: forward granularity (CLIP_AMD_HOST_SUBCHUNK) x copy piece (CLIP_AMD_HOST_COPY_PIECE) x packer threads
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=${1:-host}
 nproc
-for sc in 32 64 128 256; do echo "== subchunk $sc"; CLIP_AMD_HOST_SUBCHUNK=$sc CLIP_AMD_HOST_TIMING=1 timeout 200 python scripts/host_api_bench.py 256 2>&1 | grep -v amdgpu.ids | awk '/encode_images_from_host/ {last=$0; next} {if (last != "") print "   " last; last=""; print}' ; done 2>&1 | tee gpurun_out/${TAG}_host_api.log
-echo "== batch 1024"; CLIP_AMD_HOST_TIMING=1 timeout 200 python scripts/host_api_bench.py 1024 2>&1 | grep -v amdgpu.ids | awk '/encode_images_from_host/ {last=$0; next} {if (last != "") print "   " last; last=""; print}' | tee -a gpurun_out/${TAG}_host_api.log
-echo "== kernel tests"; timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -3
-echo "== parity tests"; timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_bench_contract.py -m gpu -q 2>&1 | tail -5
+run() { timeout 200 python scripts/host_api_bench.py $1 2>&1 | grep -v amdgpu.ids | awk '/encode_images_from_host/ {last=$0; next} {if (last != "") print "   " last; last=""; print}'; }
+for fg in 64 128 256; do echo "== forward group $fg, copy piece 32"; CLIP_AMD_HOST_SUBCHUNK=$fg CLIP_AMD_HOST_TIMING=1 run 256; done 2>&1 | tee gpurun_out/${TAG}_host_api.log
+for fg in 128 256; do echo "== batch 1024, forward group $fg"; CLIP_AMD_HOST_SUBCHUNK=$fg CLIP_AMD_HOST_TIMING=1 run 1024; done | tee -a gpurun_out/${TAG}_host_api.log
+echo "== batch 64 (defaults)"; run 64 | tee -a gpurun_out/${TAG}_host_api.log
+echo "== batch 16 (defaults)"; run 16 | tee -a gpurun_out/${TAG}_host_api.log
