@@ -59,7 +59,7 @@ API_SYMBOLS = [
     "ggml_time_init", "ggml_time_us", "ggml_time_ms",
 ]
 AMD_SYMBOLS = [
-    "clip_amd_device_count", "clip_amd_model_load", "clip_amd_model_load_multi", "clip_amd_ctx_device_count", "clip_amd_shard_bounds",
+    "clip_amd_device_count", "clip_amd_model_load", "clip_amd_model_load_multi", "clip_amd_ctx_device_count", "clip_amd_weights_from_cache", "clip_amd_shard_bounds",
     "clip_amd_gathered_embeddings", "clip_amd_ctx_device", "clip_amd_set_stream",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
@@ -93,6 +93,8 @@ def lib():
     L.clip_amd_model_load_multi.argtypes = [C.c_char_p, i32, i32]
     L.clip_amd_ctx_device_count.restype = i32
     L.clip_amd_ctx_device_count.argtypes = [vp]
+    L.clip_amd_weights_from_cache.restype = i32
+    L.clip_amd_weights_from_cache.argtypes = [vp]
     L.clip_amd_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.clip_amd_gathered_embeddings.restype = vp
     L.clip_amd_gathered_embeddings.argtypes = [vp, i32]
@@ -328,6 +330,11 @@ class Clip:
         if not lib().clip_amd_image_batch_preprocess_device(self.ctx, arr, len(keep), C.c_void_p(d_out_ptr)):
             raise RuntimeError("clip_amd_image_batch_preprocess_device failed (see stderr)")
         self.synchronize()   # `keep` (the host pixels) must outlive the copy into the pinned blob — it does: the copy is synchronous
+
+    @property
+    def weights_from_cache(self):
+        """True when this load read the repacked HBM image from CLIP_AMD_WEIGHT_CACHE instead of repacking the GGUF."""
+        return bool(lib().clip_amd_weights_from_cache(self.ctx))
 
     @property
     def n_devices(self):

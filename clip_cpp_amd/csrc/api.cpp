@@ -90,6 +90,7 @@ struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, i
     return multi_load(fname, verbosity, n_devices);
 } catch (const std::exception & e) { fprintf(stderr, "clip_amd_model_load_multi: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_amd_model_load_multi: unknown exception\n"); return nullptr; }
 int clip_amd_ctx_device_count(const struct clip_ctx * ctx) { return ctx ? multi_device_count(ctx) : 0; }
+int clip_amd_weights_from_cache(const struct clip_ctx * ctx) { return ctx && ctx->weights_from_cache ? 1 : 0; }
 void clip_amd_shard_bounds(int total, int n_devices, int device_index, int * lo, int * hi, int * rows_per_device) {
     int l = 0, h = 0, p = 0;
     if (n_devices > 0 && device_index >= 0 && device_index < n_devices && total >= 0) multi_shard(total, n_devices, device_index, &l, &h, &p);

@@ -67,6 +67,10 @@ public:
     bool get_f32(const std::string & key, float & out) const;
     bool get_bool(const std::string & key, bool & out) const;
 
+    // the mapped file (identity of its content for the repacked-weight cache, load.cpp)
+    const uint8_t * file_base() const { return (const uint8_t *)map_; }
+    size_t file_size() const { return map_size_; }
+
 private:
     void * map_ = nullptr;
     size_t map_size_ = 0;

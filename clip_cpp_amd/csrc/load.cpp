@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <memory>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "model.h"
 
@@ -117,9 +121,12 @@ void repack_rows(const RepackPlan & pl, int type, const uint8_t * src, int64_t N
 
 struct Stage {                       // host image of the device weight allocation
     std::vector<uint8_t> buf;
+    size_t size = 0;                 // bytes allocated so far (== buf.size() unless plan_only)
+    bool plan_only = false;          // lay the image out without materialising it (its content comes from the weight cache)
     size_t alloc(size_t bytes) {     // 256-byte aligned bump allocation (zero filled)
-        size_t off = (buf.size() + 255) & ~(size_t)255;
-        buf.resize(off + bytes, 0);
+        size_t off = (size + 255) & ~(size_t)255;
+        size = off + bytes;
+        if (!plan_only) buf.resize(size, 0);
         return off;
     }
 };
@@ -153,7 +160,7 @@ struct Loader {
             ts.push_back(t);
         }
         size_t off = st.alloc((size_t)expect_each * 4 * ts.size());
-        for (size_t i = 0; i < ts.size(); i++) memcpy(&st.buf[off + i * expect_each * 4], ts[i]->data, (size_t)expect_each * 4);
+        if (!st.plan_only) for (size_t i = 0; i < ts.size(); i++) memcpy(&st.buf[off + i * expect_each * 4], ts[i]->data, (size_t)expect_each * 4);
         fix((const void **)slot, off);
         return true;
     }
@@ -165,7 +172,7 @@ struct Loader {
         if (t->ne[0] != k || t->nrows() != rows) { err = "tensor " + name + ": unexpected shape"; return false; }
         size_t off = st.alloc((size_t)rows * k * 4);
         const size_t rb = ggml_row_bytes(t->type, k);
-        for (int64_t r = 0; r < rows; r++) dequantize_row(t->type, t->data + r * rb, (float *)&st.buf[off] + r * k, k);
+        if (!st.plan_only) for (int64_t r = 0; r < rows; r++) dequantize_row(t->type, t->data + r * rb, (float *)&st.buf[off] + r * k, k);
         fix((const void **)slot, off);
         return true;
     }
@@ -175,7 +182,7 @@ struct Loader {
         if (!t) return false;
         if (t->ne[0] != k || t->nrows() != rows) { err = "tensor " + name + ": unexpected shape"; return false; }
         size_t off = st.alloc(t->nbytes);
-        memcpy(&st.buf[off], t->data, t->nbytes);
+        if (!st.plan_only) memcpy(&st.buf[off], t->data, t->nbytes);
         *type = t->type;
         fix(slot, off);
         return true;
@@ -203,8 +210,9 @@ struct Loader {
         if (plan.bytes_qs) off_qs = st.alloc(plan.bytes_qs);
         if (plan.bytes_qh) off_qh = st.alloc(plan.bytes_qh);
         if (plan.bytes_dm) off_dm = st.alloc(plan.bytes_dm);
-        for (size_t i = 0; i < srcs.size(); i++)
-            repack_rows(plan, type, srcs[i], N_each, K, (int64_t)i * N_each, &st.buf[off_qs], &st.buf[off_qh], &st.buf[off_dm], &st.buf[off_w16]);
+        if (!st.plan_only)
+            for (size_t i = 0; i < srcs.size(); i++)
+                repack_rows(plan, type, srcs[i], N_each, K, (int64_t)i * N_each, &st.buf[off_qs], &st.buf[off_qh], &st.buf[off_dm], &st.buf[off_w16]);
         if (plan.bytes_w16) fix(&W.w16, off_w16);
         if (plan.bytes_qs) fix(&W.qs, off_qs);
         if (plan.bytes_qh) fix(&W.qh, off_qh);
@@ -231,6 +239,70 @@ struct Loader {
             if (!vec_f32({nm("ln2", "weight")}, &l.ln2_w, h) || !vec_f32({nm("ln2", "bias")}, &l.ln2_b, h)) return false;
         }
         return true;
+    }
+};
+
+// File "<dir>/<basename>.<key>.hbm" = 32-byte header {magic, version, key, image bytes} + the HBM image.
+struct WeightCache {
+    static constexpr uint32_t kVersion = 1;    // bump when the device layout of any tensor changes
+    bool enabled = false, readable = false;
+    std::string path;
+    uint64_t key = 0, image_bytes = 0;
+    struct Header { char magic[8]; uint32_t version, reserved; uint64_t key, image_bytes; };
+
+    static uint64_t fnv(uint64_t h, const void * p, size_t n) {
+        const uint8_t * b = (const uint8_t *)p;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+        return h;
+    }
+    void init(const GgufFile & g, const char * fname) {
+        const char * dir = getenv("CLIP_AMD_WEIGHT_CACHE");
+        if (!dir || !dir[0] || !g.file_base()) return;
+        // content identity: size, all metadata + tensor infos, the first and last 256 KB of tensor data, the layout version
+        uint64_t h = 1469598103934665603ull;
+        const uint64_t sz = g.file_size(), ver = kVersion;
+        h = fnv(h, &sz, 8);
+        h = fnv(h, &ver, 8);
+        const size_t meta = (size_t)std::min<uint64_t>(g.data_offset, sz);
+        h = fnv(h, g.file_base(), meta);
+        const size_t sample = (size_t)std::min<uint64_t>(256 << 10, sz - meta);
+        h = fnv(h, g.file_base() + meta, sample);
+        h = fnv(h, g.file_base() + sz - sample, sample);
+        key = h;
+        const char * base = strrchr(fname, '/');
+        char hex[24];
+        snprintf(hex, sizeof hex, "%016llx", (unsigned long long)key);
+        path = std::string(dir) + "/" + (base ? base + 1 : fname) + "." + hex + ".hbm";
+        enabled = true;
+        FILE * f = fopen(path.c_str(), "rb");
+        if (!f) return;
+        Header hd;
+        struct stat st;
+        if (fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "CLAMDHBM", 8) == 0 && hd.version == kVersion && hd.key == key &&
+            fstat(fileno(f), &st) == 0 && (uint64_t)st.st_size == sizeof hd + hd.image_bytes) {
+            readable = true;
+            image_bytes = hd.image_bytes;
+        }
+        fclose(f);
+    }
+    bool read_image(std::vector<uint8_t> & buf, size_t bytes) const {
+        FILE * f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        buf.resize(bytes);
+        const bool ok = fseek(f, sizeof(Header), SEEK_SET) == 0 && fread(buf.data(), 1, bytes, f) == bytes;
+        fclose(f);
+        return ok;
+    }
+    void write_image(const std::vector<uint8_t> & buf) const {   // best effort; written to a temporary name and renamed into place
+        if (!enabled) return;
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        FILE * f = fopen(tmp.c_str(), "wb");
+        if (!f) return;
+        Header hd;
+        memcpy(hd.magic, "CLAMDHBM", 8);
+        hd.version = kVersion; hd.reserved = 0; hd.key = key; hd.image_bytes = buf.size();
+        const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
     }
 };
 
@@ -304,82 +376,107 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         }
     }
 
-    Loader L(g);
-    std::string kerr;
-    if (ctx->has_text_encoder) {
-        auto & hp = ctx->text_hparams;
-        bool ok = kv_u32(g, "clip.text.embedding_length", hp.hidden_size, kerr) & kv_u32(g, "clip.text.attention.head_count", hp.n_head, kerr) &
-                  kv_u32(g, "clip.text.feed_forward_length", hp.n_intermediate, kerr) & kv_u32(g, "clip.text.block_count", hp.n_layer, kerr) &
-                  kv_u32(g, "clip.text.context_length", hp.num_positions, kerr) & kv_u32(g, "clip.text.projection_dim", hp.projection_dim, kerr);
-        if (!g.get_f32("clip.text.attention.layer_norm_epsilon", hp.eps)) { ok = false; if (kerr.empty()) kerr = "key clip.text.attention.layer_norm_epsilon not found in file"; }
-        const GgufValue * toks = g.find("tokenizer.ggml.tokens");
-        if (!toks || toks->type != GV_ARR || toks->elem_type != GV_STR) { ok = false; if (kerr.empty()) kerr = "key tokenizer.ggml.tokens not found in file"; }
-        if (!ok) return fail(kerr);
-        hp.n_vocab = (int32_t)toks->strs.size();
-        ctx->id_to_token = toks->strs;
-        ctx->token_to_id.reserve(toks->strs.size() * 2);
-        for (int32_t id = 0; id < hp.n_vocab; id++) {
-            ctx->token_to_id[toks->strs[id]] = id;   // later duplicates win, as with the reference's std::map assignment
-            ctx->max_token_len = std::max(ctx->max_token_len, toks->strs[id].size());
+    // ---- weight image: laid out (and, unless the cache holds it, filled) by the Loader ----
+    // Repacked-weight cache, opt-in: CLIP_AMD_WEIGHT_CACHE=<directory>.  The HBM image is a pure function of the GGUF
+    // content, so a file keyed by that content replaces the host-side repack (block-column-major planes, fused QKV, dequantised
+    // tables: 0.3 s for ViT-B/32 q4_0, 2 s for ViT-L/14 f16 on one core) with one sequential read; the GGUF's tensor pages are then
+    // never touched.  A missing, truncated or mismatching cache file is ignored and rewritten.
+    WeightCache cache;
+    cache.init(g, fname);
+    std::unique_ptr<Loader> Lp;
+    auto build = [&](Loader & L, std::string & why) -> bool {
+        std::string kerr;
+        ctx->vision = DevTower();
+        ctx->text = DevTower();
+        ctx->id_to_token.clear();
+        ctx->token_to_id.clear();
+        ctx->max_token_len = 0;
+        if (ctx->has_text_encoder) {
+            auto & hp = ctx->text_hparams;
+            bool ok = kv_u32(g, "clip.text.embedding_length", hp.hidden_size, kerr) & kv_u32(g, "clip.text.attention.head_count", hp.n_head, kerr) &
+                      kv_u32(g, "clip.text.feed_forward_length", hp.n_intermediate, kerr) & kv_u32(g, "clip.text.block_count", hp.n_layer, kerr) &
+                      kv_u32(g, "clip.text.context_length", hp.num_positions, kerr) & kv_u32(g, "clip.text.projection_dim", hp.projection_dim, kerr);
+            if (!g.get_f32("clip.text.attention.layer_norm_epsilon", hp.eps)) { ok = false; if (kerr.empty()) kerr = "key clip.text.attention.layer_norm_epsilon not found in file"; }
+            const GgufValue * toks = g.find("tokenizer.ggml.tokens");
+            if (!toks || toks->type != GV_ARR || toks->elem_type != GV_STR) { ok = false; if (kerr.empty()) kerr = "key tokenizer.ggml.tokens not found in file"; }
+            if (!ok) { why = kerr; return false; }
+            hp.n_vocab = (int32_t)toks->strs.size();
+            ctx->id_to_token = toks->strs;
+            ctx->token_to_id.reserve(toks->strs.size() * 2);
+            for (int32_t id = 0; id < hp.n_vocab; id++) {
+                ctx->token_to_id[toks->strs[id]] = id;   // later duplicates win, as with the reference's std::map assignment
+                ctx->max_token_len = std::max(ctx->max_token_len, toks->strs[id].size());
+            }
+            if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64)
+                { why = "unsupported text hparams (hidden/ff must be multiples of 64)"; return false; }
+            { const std::string lim = kernel_limits("text", hp.hidden_size, hp.n_head, hp.projection_dim, hp.num_positions); if (!lim.empty()) { why = lim; return false; } }
+            if (verbosity >= 2) {
+                printf("\n%s: text model hparams\n", "clip_model_load");
+                printf("n_vocab            %d\nnum_positions      %d\nt_hidden_size      %d\nt_n_intermediate   %d\n", hp.n_vocab, hp.num_positions, hp.hidden_size, hp.n_intermediate);
+                printf("t_projection_dim   %d\nt_n_head           %d\nt_n_layer          %d\n", hp.projection_dim, hp.n_head, hp.n_layer);
+            }
+            DevTower & T = ctx->text;
+            const int h = hp.hidden_size;
+            if (!L.raw("t.token_embd.weight", &T.tok_raw, &T.tok_type, h, hp.n_vocab) ||
+                !L.table_f32("t.position_embd.weight", &T.pos, h, hp.num_positions) ||
+                !L.vec_f32({"t.post_ln.weight"}, &T.post_ln_w, h) || !L.vec_f32({"t.post_ln.bias"}, &T.post_ln_b, h) ||
+                !L.linear({"text_projection.weight"}, T.proj, h, hp.projection_dim) ||
+                !L.layers("t", hp.n_layer, h, hp.n_intermediate, T.layers))
+                { why = L.err; return false; }
         }
-        if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64)
-            return fail("unsupported text hparams (hidden/ff must be multiples of 64)");
-        { const std::string why = kernel_limits("text", hp.hidden_size, hp.n_head, hp.projection_dim, hp.num_positions); if (!why.empty()) return fail(why); }
-        if (verbosity >= 2) {
-            printf("\n%s: text model hparams\n", "clip_model_load");
-            printf("n_vocab            %d\nnum_positions      %d\nt_hidden_size      %d\nt_n_intermediate   %d\n", hp.n_vocab, hp.num_positions, hp.hidden_size, hp.n_intermediate);
-            printf("t_projection_dim   %d\nt_n_head           %d\nt_n_layer          %d\n", hp.projection_dim, hp.n_head, hp.n_layer);
+        if (ctx->has_vision_encoder) {
+            auto & hp = ctx->vision_hparams;
+            bool ok = kv_u32(g, "clip.vision.embedding_length", hp.hidden_size, kerr) & kv_u32(g, "clip.vision.attention.head_count", hp.n_head, kerr) &
+                      kv_u32(g, "clip.vision.feed_forward_length", hp.n_intermediate, kerr) & kv_u32(g, "clip.vision.block_count", hp.n_layer, kerr) &
+                      kv_u32(g, "clip.vision.image_size", hp.image_size, kerr) & kv_u32(g, "clip.vision.patch_size", hp.patch_size, kerr) &
+                      kv_u32(g, "clip.vision.projection_dim", hp.projection_dim, kerr);
+            if (!g.get_f32("clip.vision.attention.layer_norm_epsilon", hp.eps)) { ok = false; if (kerr.empty()) kerr = "key clip.vision.attention.layer_norm_epsilon not found in file"; }
+            const GgufValue * mean = g.find("clip.vision.image_mean");
+            const GgufValue * stdv = g.find("clip.vision.image_std");
+            if (!mean || !stdv || mean->type != GV_ARR || stdv->type != GV_ARR || mean->elem_type != GV_F32 || stdv->elem_type != GV_F32 ||
+                mean->count < 3 || stdv->count < 3) { ok = false; if (kerr.empty()) kerr = "key clip.vision.image_mean/std not found in file"; }
+            if (!ok) { why = kerr; return false; }
+            memcpy(ctx->image_mean, mean->raw.data(), 12);
+            memcpy(ctx->image_std, stdv->raw.data(), 12);
+            if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64 ||
+                hp.patch_size <= 0 || hp.image_size % hp.patch_size)
+                { why = "unsupported vision hparams (hidden/ff must be multiples of 64)"; return false; }
+            { const int g_ = hp.image_size / hp.patch_size; const std::string lim = kernel_limits("vision", hp.hidden_size, hp.n_head, hp.projection_dim, g_ * g_ + 1); if (!lim.empty()) { why = lim; return false; } }
+            if (verbosity >= 2) {
+                printf("\n%s: vision model hparams\n", "clip_model_load");
+                printf("image_size         %d\npatch_size         %d\nv_hidden_size      %d\nv_n_intermediate   %d\n", hp.image_size, hp.patch_size, hp.hidden_size, hp.n_intermediate);
+                printf("v_projection_dim   %d\nv_n_head           %d\nv_n_layer          %d\n", hp.projection_dim, hp.n_head, hp.n_layer);
+            }
+            DevTower & V = ctx->vision;
+            const int h = hp.hidden_size, P = hp.patch_size, Gd = hp.image_size / P, T = Gd * Gd + 1;
+            const GgufTensorInfo * pe = L.need("v.patch_embd.weight");
+            if (!pe) { why = L.err; return false; }
+            if (pe->type != GT_F16 && pe->type != GT_F32) { why = "v.patch_embd.weight must be f16"; return false; }
+            if (!L.linear({"v.patch_embd.weight"}, V.patch, 3 * P * P, h, /*as_conv=*/true) ||
+                !L.vec_f32({"v.class_embd"}, &V.class_embd, h) ||
+                !L.table_f32("v.position_embd.weight", &V.pos, h, T) ||
+                !L.vec_f32({"v.pre_ln.weight"}, &V.pre_ln_w, h) || !L.vec_f32({"v.pre_ln.bias"}, &V.pre_ln_b, h) ||
+                !L.vec_f32({"v.post_ln.weight"}, &V.post_ln_w, h) || !L.vec_f32({"v.post_ln.bias"}, &V.post_ln_b, h) ||
+                !L.linear({"visual_projection.weight"}, V.proj, h, hp.projection_dim) ||
+                !L.layers("v", hp.n_layer, h, hp.n_intermediate, V.layers))
+                { why = L.err; return false; }
         }
-        DevTower & T = ctx->text;
-        const int h = hp.hidden_size;
-        if (!L.raw("t.token_embd.weight", &T.tok_raw, &T.tok_type, h, hp.n_vocab) ||
-            !L.table_f32("t.position_embd.weight", &T.pos, h, hp.num_positions) ||
-            !L.vec_f32({"t.post_ln.weight"}, &T.post_ln_w, h) || !L.vec_f32({"t.post_ln.bias"}, &T.post_ln_b, h) ||
-            !L.linear({"text_projection.weight"}, T.proj, h, hp.projection_dim) ||
-            !L.layers("t", hp.n_layer, h, hp.n_intermediate, T.layers))
-            return fail(L.err);
+        return true;
+    };
+    for (int attempt = 0; attempt < 2; attempt++) {
+        Lp.reset(new Loader(g));
+        Lp->st.plan_only = cache.readable;
+        std::string why;
+        if (!build(*Lp, why)) return fail(why);
+        if (!Lp->st.plan_only) break;
+        if (cache.image_bytes == Lp->st.size) break;   // the cached image has the planned size: use it
+        cache.readable = false;                          // layout changed (another library version wrote it): rebuild and overwrite
     }
-    if (ctx->has_vision_encoder) {
-        auto & hp = ctx->vision_hparams;
-        bool ok = kv_u32(g, "clip.vision.embedding_length", hp.hidden_size, kerr) & kv_u32(g, "clip.vision.attention.head_count", hp.n_head, kerr) &
-                  kv_u32(g, "clip.vision.feed_forward_length", hp.n_intermediate, kerr) & kv_u32(g, "clip.vision.block_count", hp.n_layer, kerr) &
-                  kv_u32(g, "clip.vision.image_size", hp.image_size, kerr) & kv_u32(g, "clip.vision.patch_size", hp.patch_size, kerr) &
-                  kv_u32(g, "clip.vision.projection_dim", hp.projection_dim, kerr);
-        if (!g.get_f32("clip.vision.attention.layer_norm_epsilon", hp.eps)) { ok = false; if (kerr.empty()) kerr = "key clip.vision.attention.layer_norm_epsilon not found in file"; }
-        const GgufValue * mean = g.find("clip.vision.image_mean");
-        const GgufValue * stdv = g.find("clip.vision.image_std");
-        if (!mean || !stdv || mean->type != GV_ARR || stdv->type != GV_ARR || mean->elem_type != GV_F32 || stdv->elem_type != GV_F32 ||
-            mean->count < 3 || stdv->count < 3) { ok = false; if (kerr.empty()) kerr = "key clip.vision.image_mean/std not found in file"; }
-        if (!ok) return fail(kerr);
-        memcpy(ctx->image_mean, mean->raw.data(), 12);
-        memcpy(ctx->image_std, stdv->raw.data(), 12);
-        if (hp.hidden_size <= 0 || hp.n_head <= 0 || hp.hidden_size % hp.n_head || hp.hidden_size % 64 || hp.n_intermediate % 64 ||
-            hp.patch_size <= 0 || hp.image_size % hp.patch_size)
-            return fail("unsupported vision hparams (hidden/ff must be multiples of 64)");
-        { const int g_ = hp.image_size / hp.patch_size; const std::string why = kernel_limits("vision", hp.hidden_size, hp.n_head, hp.projection_dim, g_ * g_ + 1); if (!why.empty()) return fail(why); }
-        if (verbosity >= 2) {
-            printf("\n%s: vision model hparams\n", "clip_model_load");
-            printf("image_size         %d\npatch_size         %d\nv_hidden_size      %d\nv_n_intermediate   %d\n", hp.image_size, hp.patch_size, hp.hidden_size, hp.n_intermediate);
-            printf("v_projection_dim   %d\nv_n_head           %d\nv_n_layer          %d\n", hp.projection_dim, hp.n_head, hp.n_layer);
-        }
-        DevTower & V = ctx->vision;
-        const int h = hp.hidden_size, P = hp.patch_size, Gd = hp.image_size / P, T = Gd * Gd + 1;
-        const GgufTensorInfo * pe = L.need("v.patch_embd.weight");
-        if (!pe) return fail(L.err);
-        if (pe->type != GT_F16 && pe->type != GT_F32) return fail("v.patch_embd.weight must be f16");
-        if (!L.linear({"v.patch_embd.weight"}, V.patch, 3 * P * P, h, /*as_conv=*/true) ||
-            !L.vec_f32({"v.class_embd"}, &V.class_embd, h) ||
-            !L.table_f32("v.position_embd.weight", &V.pos, h, T) ||
-            !L.vec_f32({"v.pre_ln.weight"}, &V.pre_ln_w, h) || !L.vec_f32({"v.pre_ln.bias"}, &V.pre_ln_b, h) ||
-            !L.vec_f32({"v.post_ln.weight"}, &V.post_ln_w, h) || !L.vec_f32({"v.post_ln.bias"}, &V.post_ln_b, h) ||
-            !L.linear({"visual_projection.weight"}, V.proj, h, hp.projection_dim) ||
-            !L.layers("v", hp.n_layer, h, hp.n_intermediate, V.layers))
-            return fail(L.err);
-    }
+    Loader & L = *Lp;
     if (verbosity >= 1) {
         printf("%s: text_encoder:   %d\n", "clip_model_load", ctx->has_text_encoder);
         printf("%s: vision_encoder: %d\n", "clip_model_load", ctx->has_vision_encoder);
-        printf("%s: model size:     %.2f MB (HBM image, repacked)\n", "clip_model_load", L.st.buf.size() / 1024.0 / 1024.0);
+        printf("%s: model size:     %.2f MB (HBM image, repacked)\n", "clip_model_load", L.st.size / 1024.0 / 1024.0);
     }
 
     // ---- device ----
@@ -391,6 +488,8 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         if (allow && allow[0] == '1') {
             if (verbosity >= 1) fprintf(stderr, "clip_model_load: no HIP device — host-only context (tokenizer / preprocessing only; encoders will fail)\n");
             ctx->device = -1;
+            if (L.st.plan_only) ctx->weights_from_cache = true;   // (a valid cache file exists; nothing to upload here)
+            else cache.write_image(L.st.buf);                     // a GPU-less machine can pre-build the cache
             return ctx;
         }
         return fail("no HIP device available: this library has no CPU fallback (set CLIP_AMD_ALLOW_NO_DEVICE=1 for a host-only context)");
@@ -409,10 +508,22 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         ctx->sk_ws = (float *)w; ctx->sk_ws_floats = nfl; ctx->sk_cnt = (unsigned *)c; ctx->sk_cnt_n = 4096;
         if (hipMalloc((void **)&ctx->sk_stats, (size_t)2 * 128 * 128 * sizeof(float2)) != hipSuccess) return fail("hipMalloc (LayerNorm statistics) failed");
     }
-    ctx->weights_bytes = L.st.buf.size() + 256;
+    ctx->weights_bytes = L.st.size + 256;
     if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");
-    if (hipMemcpy(ctx->weights_base, L.st.buf.data(), L.st.buf.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("weight upload failed");
-    for (const Fix & f : L.fixes) *f.slot = (const uint8_t *)ctx->weights_base + f.off;
+    if (L.st.plan_only) {
+        if (!cache.read_image(L.st.buf, L.st.size)) {
+            // unreadable after all (truncated behind our back): fall back to the GGUF
+            Lp.reset(new Loader(g));
+            std::string why;
+            if (!build(*Lp, why)) return fail(why);
+        } else {
+            ctx->weights_from_cache = true;
+        }
+    }
+    Loader & LL = *Lp;
+    if (hipMemcpy(ctx->weights_base, LL.st.buf.data(), LL.st.size, hipMemcpyHostToDevice) != hipSuccess) return fail("weight upload failed");
+    if (!ctx->weights_from_cache) cache.write_image(LL.st.buf);
+    for (const Fix & f : LL.fixes) *f.slot = (const uint8_t *)ctx->weights_base + f.off;
     if (verbosity >= 1) printf("\n%s: %zu MB of HBM allocated for weights on device %d\n", "clip_model_load", ctx->weights_bytes / 1024 / 1024, device);
     return ctx;
 }

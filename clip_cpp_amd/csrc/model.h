@@ -99,6 +99,7 @@ struct clip_ctx {
     hipStream_t stream = nullptr;    // stream in use (own or user-provided)
     void * weights_base = nullptr;   // one HBM allocation holding every tensor
     size_t weights_bytes = 0;
+    bool weights_from_cache = false;      // the HBM image came from the repacked-weight cache (CLIP_AMD_WEIGHT_CACHE), not from a repack
     clipamd::DevTower vision, text;
     clipamd::Workspace ws;           // activations, grown on demand
     void * pinned = nullptr;         // pinned host staging

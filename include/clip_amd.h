@@ -33,6 +33,12 @@ struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int dev
 struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, int n_devices);
 /* Number of devices behind a handle (1 for clip_model_load / clip_amd_model_load handles). */
 int clip_amd_ctx_device_count(const struct clip_ctx * ctx);
+
+/* Repacked-weight cache (replaces the per-load tensor read + repack of reference clip.cpp:435-461).  Opt-in through the
+ * environment: CLIP_AMD_WEIGHT_CACHE=<directory>.  clip_model_load then keeps "<directory>/<file name>.<content key>.hbm" — the exact
+ * HBM image of the model — and later loads of the same file content read that image instead of repacking the GGUF tensors.
+ * Returns 1 when this context's weights came from the cache, 0 when they were repacked from the GGUF. */
+int clip_amd_weights_from_cache(const struct clip_ctx * ctx);
 /* The shard clip_image_batch_encode gives device `device_index` of `n_devices` for a batch of `total` images: rows
  * [*lo, *hi), and the padded per-device row count of the all-gather (pure arithmetic, no device needed). */
 void clip_amd_shard_bounds(int total, int n_devices, int device_index, int * lo, int * hi, int * rows_per_device);

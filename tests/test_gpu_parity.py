@@ -358,6 +358,27 @@ def test_zero_shot_scoring_kernel_vs_reference_arithmetic(gpu, fixture_cache, B,
             assert p3 == p1 + 1
 
 
+def test_load_from_repacked_weight_cache_encodes_bit_identically(gpu, fixture_cache, tmp_path, monkeypatch):
+    """the cached HBM image IS the repacked image — same embeddings to the last bit, both towers, a quantised file
+    (planes + dequantised tables + raw token table) and an f16 one."""
+    for ftype in ("q4_0", "f16"):
+        p = fixtures.cached_model(fixture_cache, "tiny14", ftype)
+        imgs = fixtures.synthetic_images(3, 28, seed=3)
+        toks = [[49406, 320, 1125, 539, 320, 2368, 49407], [49406, 49407]]
+        monkeypatch.delenv("CLIP_AMD_WEIGHT_CACHE", raising=False)
+        plain = gpu.Clip(p, device=0)
+        want_i, want_t = plain.encode_images(imgs), plain.encode_texts(toks)
+        plain.close()
+        monkeypatch.setenv("CLIP_AMD_WEIGHT_CACHE", str(tmp_path))
+        first = gpu.Clip(p, device=0)
+        assert not first.weights_from_cache
+        first.close()
+        cached = gpu.Clip(p, device=0)
+        assert cached.weights_from_cache
+        assert np.array_equal(cached.encode_images(imgs), want_i) and np.array_equal(cached.encode_texts(toks), want_t)
+        cached.close()
+
+
 def test_graph_replay_is_bitwise_identical_to_eager(gpu, fixture_cache):
     """Small batches are captured into a hipGraph on the 2nd call with the same signature and replayed afterwards:
     eager (1st) == capture (2nd) == replay (3rd...), and a replay sees new pixel data written into the same buffers."""

@@ -253,6 +253,55 @@ def test_product_side_synthetic_models_load_everywhere(tmp_path, clip_lib):
             os.environ.pop("CLIP_AMD_ALLOW_NO_DEVICE", None)
 
 
+def test_repacked_weight_cache_keyed_by_content(clip_lib, tmp_path, fixture_cache, host_only_env, monkeypatch):
+    """CLIP_AMD_WEIGHT_CACHE=<dir> keeps the HBM image of a model; a later load of the same content uses it, a truncated
+    or foreign file is ignored and rewritten, another file content gets another key.  (Host-only contexts: layout and file handling;
+    the GPU tier checks that a cached load encodes bit-identically.)"""
+    import glob
+    import shutil
+    cache = tmp_path / "wcache"
+    cache.mkdir()
+    monkeypatch.setenv("CLIP_AMD_WEIGHT_CACHE", str(cache))
+    src = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    a = tmp_path / "model_a.gguf"
+    shutil.copy(src, a)
+    c = clip_lib.Clip(str(a), verbosity=0)
+    assert not c.weights_from_cache
+    files = glob.glob(str(cache / "model_a.gguf.*.hbm"))
+    assert len(files) == 1 and os.path.getsize(files[0]) > 32
+    c.close()
+    c = clip_lib.Clip(str(a), verbosity=0)
+    assert c.weights_from_cache and c.tokenize("a b")[0] == 49406       # everything outside the weight image is still read from the GGUF
+    c.close()
+    # truncated cache file: ignored, rebuilt, usable again
+    size = os.path.getsize(files[0])
+    with open(files[0], "r+b") as f:
+        f.truncate(size // 2)
+    c = clip_lib.Clip(str(a), verbosity=0)
+    assert not c.weights_from_cache
+    c.close()
+    assert os.path.getsize(files[0]) == size
+    # foreign bytes under the right name (wrong magic): ignored
+    with open(files[0], "r+b") as f:
+        f.write(b"NOTACACHE")
+    c = clip_lib.Clip(str(a), verbosity=0)
+    assert not c.weights_from_cache
+    c.close()
+    # other content (another quantisation of the same architecture), same file name in another directory -> another key
+    other = tmp_path / "sub"
+    other.mkdir()
+    shutil.copy(fixtures.cached_model(fixture_cache, "tiny", "q8_0"), other / "model_a.gguf")
+    c = clip_lib.Clip(str(other / "model_a.gguf"), verbosity=0)
+    assert not c.weights_from_cache
+    c.close()
+    assert len(glob.glob(str(cache / "model_a.gguf.*.hbm"))) == 2
+    # without the variable nothing is read or written
+    monkeypatch.delenv("CLIP_AMD_WEIGHT_CACHE")
+    c = clip_lib.Clip(str(a), verbosity=0)
+    assert not c.weights_from_cache
+    c.close()
+
+
 def test_malformed_and_unsupported_files_are_rejected_at_load(clip_lib, tmp_path, host_only_env, capfd):
     """(a) tensor shapes whose element count wraps int64 must not pass the bounds check; (b) models outside the
     kernels' limits (hidden_size > 2048, projection_dim % 4, unsupported head size, too many tokens) fail at LOAD with a message,
