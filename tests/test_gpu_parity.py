@@ -235,6 +235,25 @@ def test_large_model_shapes_quantised(gpu, fixture_cache, config, ftype):
     assert one_minus_cos(clip.encode_images(imgs[:1]), got[:1])[0] <= 1e-6
 
 
+@pytest.mark.parametrize("ftype", ["f16", "q5_1"])
+def test_vit_l14_batch130_largest_m_kernels_match_single_images(gpu, fixture_cache, ftype):
+    """130 ViT-L/14 images = 33410 token rows: the regime of the 256 x 256 four-wave GEMM (k_gemm4.hip) with its whole-rounds split
+    and, for block-quantised files, of the per-layer fp16 weight panels.  No oracle run at this size: batch invariance against
+    single-image forwards (other kernels, other tiles: equal up to fp32 re-association of split-K and fp16 activation roundings)
+    and run-to-run determinism."""
+    p = fixtures.cached_model(fixture_cache, "l14", ftype, text=False, vision=True)
+    clip = gpu.Clip(p, device=0)
+    imgs = fixtures.synthetic_images(130, 224, seed=57)
+    full = clip.encode_images(imgs)
+    assert full.shape[0] == 130 and np.all(np.isfinite(full))
+    np.testing.assert_allclose(np.linalg.norm(full, axis=1), 1.0, atol=1e-5)
+    assert np.array_equal(clip.encode_images(imgs), full)
+    for i in (0, 64, 129):
+        one = clip.encode_images(imgs[i:i + 1])
+        assert one_minus_cos(one, full[i:i + 1])[0] <= 1e-6, i
+        np.testing.assert_allclose(one[0], full[i], atol=3e-4)
+
+
 def test_batches_beyond_one_workspace_chunk_and_stream_restore(gpu, fixture_cache):
     """More images than one forward chunk (1024) and than one host-API staging chunk (256): rows must equal the small-batch
     results bit for bit (tiny model: no split-K at any size); clip_amd_set_stream(NULL) restores the context's own stream."""
