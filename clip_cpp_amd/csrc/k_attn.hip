@@ -276,12 +276,15 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
     // feeds two MFMAs, halving the LDS traffic that bounds this kernel at T = 257), the odd last block alone.
     constexpr int QB = (NT >= 7 && NT <= 18) ? 2 : 1;
     const AttnTile<NT, DKS, DT> t{Ks, Vt, Qg, p.out + (size_t)row0 * p.h + head * DH, ld, p.h, len, p.causal, fq, fg};
+    // gridDim.y workgroups share one (sequence, head): each stages K / V^T itself and takes every gridDim.y-th set of four work units
+    // (few sequences x heads and many query blocks — one ViT-L/14 image is 16 workgroups of 17 query blocks otherwise)
+    const int slot = wave + 4 * blockIdx.y, nslot = 4 * gridDim.y;
     if constexpr (QB == 2) {
         const int npair = nqb >> 1;
-        for (int u = wave; u < npair; u += 4) attn_blocks<NT, DKS, DT, 2>(t, 2 * u);
-        if ((nqb & 1) && wave == (npair & 3)) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
+        for (int u = slot; u < npair; u += nslot) attn_blocks<NT, DKS, DT, 2>(t, 2 * u);
+        if ((nqb & 1) && slot == npair % nslot) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
     } else {
-        for (int qb = wave; qb < nqb; qb += 4) attn_blocks<NT, DKS, DT, 1>(t, qb);
+        for (int qb = slot; qb < nqb; qb += nslot) attn_blocks<NT, DKS, DT, 1>(t, qb);
     }
 }
 
@@ -291,7 +294,12 @@ void launch_inst(const AttnParams & p, int nseq, hipStream_t stream) {
     static_assert(smem <= 160 * 1024, "attention tile does not fit the LDS");
     static unsigned long long lds_ok = 0;
     if (smem > 64 * 1024) opt_in_dynamic_lds(attn_kernel<NT, DKS, DT>, smem, lds_ok);
-    hipLaunchKernelGGL((attn_kernel<NT, DKS, DT>), dim3(nseq * p.n_head), dim3(256), smem, stream, p);
+    // query split: only where (sequence, head) pairs alone leave most CUs idle and a pair has more work units than one workgroup's 4 waves
+    constexpr int QB = (NT >= 7 && NT <= 18) ? 2 : 1;
+    const int units = (NT + QB - 1) / QB;
+    int qs = 1;
+    if (nseq * p.n_head <= 64 && units > 4) qs = (units + 3) / 4 < 4 ? (units + 3) / 4 : 4;
+    hipLaunchKernelGGL((attn_kernel<NT, DKS, DT>), dim3(nseq * p.n_head, qs), dim3(256), smem, stream, p);
 }
 
 template <int DKS, int DT>
