@@ -400,8 +400,9 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
     // the largest problems (ViT-L/14 at batch 256: 65792 rows; ViT-B/32 from batch ~700): 256 x 256 tiles, four waves of 128 x 128 with
     // the accumulators in AGPRs (k_gemm4.hip), on the tile rows that fill whole rounds of 256 workgroups + a second launch for the rest.
     // Sustained (200 launches, profiles/r02_gemm8_experiments.txt section 11): l14.qkv 447 us vs 468 (160 x 256) / 485 (160 x 128),
-    // l14.down 542 vs 579 / 607, l14.up 645 vs 652 / 705.
-    if (M >= 32768 && wgs(256, 256) >= 3 * 256) return 256260;
+    // l14.down 542 vs 579 / 607, l14.up 645 vs 652 / 705; at 32896 rows (batch 128): qkv 223 vs 238 / 241, down 287 vs 321 / 333,
+    // out 110 vs 117 / 107, up 333 vs 332 / 360.  From two rounds of tiles up.
+    if (M >= 32768 && wgs(256, 256) >= 2 * 256) return 256260;
     {
         const int t8 = wgs(160, 256);
         const float rounds = (float)t8 / 256.f;

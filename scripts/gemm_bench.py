@@ -24,6 +24,7 @@ SHAPES = [  # (name, M, N, K, epi)
     ("b64.qkv", 3200, 2304, 768, 1), ("b64.out", 3200, 768, 768, 4), ("b64.up", 3200, 3072, 768, 3), ("b64.down", 3200, 768, 3072, 4),
     ("b1024.qkv", 51200, 2304, 768, 1), ("b1024.out", 51200, 768, 768, 4), ("b1024.up", 51200, 3072, 768, 3), ("b1024.down", 51200, 768, 3072, 4),
     ("l14.b1.qkv", 257, 3072, 1024, 1), ("l14.b1.out", 257, 1024, 1024, 4), ("l14.b1.up", 257, 4096, 1024, 3), ("l14.b1.down", 257, 1024, 4096, 4),
+    ("l14.b128.qkv", 32896, 3072, 1024, 1), ("l14.b128.out", 32896, 1024, 1024, 4), ("l14.b128.up", 32896, 4096, 1024, 3), ("l14.b128.down", 32896, 1024, 4096, 4),
     ("sq.k1k", 4096, 4096, 1024, 1), ("sq.k8k", 4096, 4096, 8192, 1), ("sq8.k4k", 8192, 8192, 4096, 1),
     ("b128.qkv", 6400, 2304, 768, 1), ("b128.out", 6400, 768, 768, 4), ("b128.up", 6400, 3072, 768, 3), ("b128.down", 6400, 768, 3072, 4),
 ]
