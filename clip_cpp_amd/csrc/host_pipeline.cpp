@@ -14,6 +14,9 @@
 //    device 0 into the caller's `vec`.  RCCL is bound with dlopen at load time, so single-GPU users of libclip.so do not need it.
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +79,60 @@ bool grow_device(void *& p, size_t & have, size_t want) {
 
 }  // namespace
 
+// Packer threads that live as long as the context: spawning 15 threads per chunk cost ~0.5 ms per 256 images (a tenth of the call).
+// run(P, fn) executes fn(0) on the caller and fn(1) .. fn(P-1) on pool threads and returns when all are done.
+struct PackPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::function<void(int)> job;
+    unsigned long generation = 0;
+    int want = 0, running = 0;
+    bool stop = false;
+
+    void worker(int idx) {
+        unsigned long seen = 0;
+        for (;;) {
+            std::function<void(int)> fn;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || (generation != seen && idx < want); });
+                if (stop) return;
+                seen = generation;
+                fn = job;
+            }
+            fn(idx + 1);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--running == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(int P, const std::function<void(int)> & fn) {
+        const int helpers = P - 1;
+        if (helpers > 0) {
+            std::lock_guard<std::mutex> lk(m);
+            while ((int)th.size() < helpers) { const int idx = (int)th.size(); th.emplace_back([this, idx] { worker(idx); }); }
+            job = fn;
+            want = helpers;
+            running = helpers;
+            generation++;
+        }
+        if (helpers > 0) cv.notify_all();
+        fn(0);
+        if (helpers > 0) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return running == 0; });
+            want = 0;
+        }
+    }
+    ~PackPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto & t : th) t.join();
+    }
+};
+
 // Two granularities.  COPY pieces (32 images, ~10 MB of fp16): a piece's H2D is queued the moment the packers have filled it, so the
 // copy engine trails the packers by one piece.  FORWARD groups: the vision tower runs once per group, after the group's last piece has
 // landed.  r02 first ran the tower per 128-image piece (pack || copy || forward), but the tower's per-image rate at 128 images is 58k/s
@@ -127,60 +184,109 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
             return false;
         }
     }
-    const int P = std::max(1, std::min({n_threads, 16, n / 8}));   // >= 8 images (4.8 MB) per packer thread: below that the spawn costs more than the copy
+    const int P = std::max(1, std::min({n_threads, 16, n / 8}));   // >= 8 images (4.8 MB) per packer thread: below that the hand-off costs more than the copy
     bool ok = true;
     static const bool timing = getenv("CLIP_AMD_HOST_TIMING") != nullptr;     // stderr: where a call's host time goes
     const auto t_begin = std::chrono::steady_clock::now();
     double t_wait_pack = 0, t_enqueue = 0;
-    for (int c = 0; c < n_chunks && ok; c++) {
-        const int b0 = c * chunk, bc = std::min(chunk, n - b0), buf = c & 1;
-        uint16_t * pin = (uint16_t *)hp.pin_in[buf];
-        uint16_t * dev = (uint16_t *)hp.dev_in[buf];
-        if (c >= 2) {
-            ok = ok && hipEventSynchronize(hp.ev_copied[buf]) == hipSuccess;                           // pinned buffer: H2Ds of chunk c-2 done
-            ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;        // device buffer: forwards of chunk c-2 done
-        } else if (hp.used[buf]) {
-            // first use in this call of a buffer an earlier call may still be reading (device side only: calls end synchronised
-            // on the host side, so the pinned buffer is free)
-            ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;
+
+    // Per-chunk geometry (the same for every chunk but the last) and packing progress: packed[c][piece] counts converted images;
+    // go[c] opens chunk c's pinned buffer to the packers (chunks 0 and 1 at once, chunk c >= 2 when the H2Ds of chunk c-2 are done).
+    struct ChunkGeo { int b0, bc, fg, cp, ppg, n_grp; };
+    std::vector<ChunkGeo> geo(n_chunks);
+    std::vector<std::vector<std::atomic<int>>> packed(n_chunks);
+    std::vector<std::atomic<int>> go(n_chunks);
+    for (int c = 0; c < n_chunks; c++) {
+        ChunkGeo & g = geo[c];
+        g.b0 = c * chunk;
+        g.bc = std::min(chunk, n - g.b0);
+        g.fg = host_pipeline_subchunk(g.bc, n_chunks > 1);   // images per forward
+        g.cp = host_pipeline_copy_piece(g.fg);               // images per H2D copy (pieces never straddle a forward group)
+        g.ppg = (g.fg + g.cp - 1) / g.cp;                    // pieces per (full) forward group
+        g.n_grp = (g.bc + g.fg - 1) / g.fg;
+        packed[c] = std::vector<std::atomic<int>>((size_t)g.n_grp * g.ppg);
+        for (auto & a : packed[c]) a.store(0, std::memory_order_relaxed);
+        go[c].store(c < 2 ? 1 : 0, std::memory_order_relaxed);
+    }
+    std::atomic<bool> abort_pack{false};
+    auto pack = [&](int t) {
+        for (int c = 0; c < n_chunks; c++) {
+            while (!go[c].load(std::memory_order_acquire)) {
+                if (abort_pack.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const ChunkGeo & g = geo[c];
+            uint16_t * pin = (uint16_t *)hp.pin_in[c & 1];
+            for (int i = t; i < g.bc; i += P) {                 // image i of the chunk; pieces fill in order
+                cvt_f16(imgs[g.b0 + i].data, pin + per * i, per);
+                packed[c][(size_t)(i / g.fg) * g.ppg + (i % g.fg) / g.cp].fetch_add(1, std::memory_order_release);
+            }
         }
-        hp.used[buf] = true;
-        const int fg = host_pipeline_subchunk(bc, n_chunks > 1);   // images per forward
-        const int cp = host_pipeline_copy_piece(fg);        // images per H2D copy (pieces never straddle a forward group)
-        const int ppg = (fg + cp - 1) / cp;                 // pieces per (full) forward group
-        const int n_grp = (bc + fg - 1) / fg;
-        std::vector<std::atomic<int>> packed((size_t)n_grp * ppg);
-        for (auto & a : packed) a.store(0, std::memory_order_relaxed);
-        auto pack = [&](int t) {
-            for (int i = t; i < bc; i += P) {                 // image i of the chunk; pieces fill in order
-                cvt_f16(imgs[b0 + i].data, pin + per * i, per);
-                packed[(size_t)(i / fg) * ppg + (i % fg) / cp].fetch_add(1, std::memory_order_release);
+    };
+    // the calling thread drives the device side; its share of the packing (t = 0) is done piecewise while it waits
+    auto drive = [&]() {
+        for (int c = 0; c < n_chunks && ok; c++) {
+            const ChunkGeo & g = geo[c];
+            const int buf = c & 1;
+            uint16_t * pin = (uint16_t *)hp.pin_in[buf];
+            uint16_t * dev = (uint16_t *)hp.dev_in[buf];
+            if (c >= 2) {
+                ok = ok && hipEventSynchronize(hp.ev_copied[buf]) == hipSuccess;                           // pinned buffer: H2Ds of chunk c-2 done
+                ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;        // device buffer: forwards of chunk c-2 done
+                go[c].store(1, std::memory_order_release);
+            } else if (hp.used[buf]) {
+                // first use in this call of a buffer an earlier call may still be reading (device side only: calls end synchronised
+                // on the host side, so the pinned buffer is free)
+                ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;
+            }
+            hp.used[buf] = true;
+            for (int gi = 0; gi < g.n_grp && ok; gi++) {
+                const int g0 = gi * g.fg, gn = std::min(g.fg, g.bc - g0);
+                for (int k = 0; k * g.cp < gn && ok; k++) {
+                    const int s0 = g0 + k * g.cp, sn = std::min(g.cp, g0 + gn - s0);
+                    const auto tw0 = std::chrono::steady_clock::now();
+                    while (packed[c][(size_t)gi * g.ppg + k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
+                    t_wait_pack += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+                    ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
+                }
+                const auto tw1 = std::chrono::steady_clock::now();
+                ok = ok && hipEventRecord(hp.ev_sub, hp.copy_stream) == hipSuccess;
+                ok = ok && hipStreamWaitEvent(ctx->stream, hp.ev_sub, 0) == hipSuccess;
+                ctx->input_f16 = true;
+                ok = ok && vision_forward_device(ctx, (const float *)(dev + per * g0), gn, d_out + (size_t)(g.b0 + g0) * proj, normalize);
+                ctx->input_f16 = false;
+                t_enqueue += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
+            }
+            ok = ok && hipEventRecord(hp.ev_copied[buf], hp.copy_stream) == hipSuccess;
+            ok = ok && hipEventRecord(hp.ev_consumed[buf], ctx->stream) == hipSuccess;
+        }
+        if (!ok) abort_pack.store(true);
+        for (int c = 0; c < n_chunks; c++) go[c].store(1, std::memory_order_release);   // (error path: let the packers run out)
+    };
+    if (P == 1) {
+        // no helpers: the caller packs a chunk, then drives it (no overlap inside a chunk; chunk c+1's pack still overlaps chunk c's forward)
+        for (int c = 0; c < n_chunks; c++) go[c].store(1, std::memory_order_relaxed);
+        pack(0);
+        drive();
+    } else {
+        if (!hp.pool) hp.pool = new PackPool();
+        // fn(0) = the driver on the calling thread; fn(1..P-1) = packers with ids 0..P-2 of a (P-1)-way split
+        const int Pp = P - 1;
+        auto packer = [&, Pp](int t) {
+            for (int c = 0; c < n_chunks; c++) {
+                while (!go[c].load(std::memory_order_acquire)) {
+                    if (abort_pack.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                const ChunkGeo & g = geo[c];
+                uint16_t * pin = (uint16_t *)hp.pin_in[c & 1];
+                for (int i = t; i < g.bc; i += Pp) {
+                    cvt_f16(imgs[g.b0 + i].data, pin + per * i, per);
+                    packed[c][(size_t)(i / g.fg) * g.ppg + (i % g.fg) / g.cp].fetch_add(1, std::memory_order_release);
+                }
             }
         };
-        std::vector<std::thread> pool;
-        if (P > 1 && bc >= 8) for (int t = 1; t < P; t++) pool.emplace_back(pack, t);
-        else { for (int t = 1; t < P; t++) pack(t); }
-        pack(0);
-        for (int g = 0; g < n_grp && ok; g++) {
-            const int g0 = g * fg, gn = std::min(fg, bc - g0);
-            for (int k = 0; k * cp < gn && ok; k++) {
-                const int s0 = g0 + k * cp, sn = std::min(cp, g0 + gn - s0);
-                const auto tw0 = std::chrono::steady_clock::now();
-                while (packed[(size_t)g * ppg + k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
-                t_wait_pack += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
-                ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
-            }
-            const auto tw1 = std::chrono::steady_clock::now();
-            ok = ok && hipEventRecord(hp.ev_sub, hp.copy_stream) == hipSuccess;
-            ok = ok && hipStreamWaitEvent(ctx->stream, hp.ev_sub, 0) == hipSuccess;
-            ctx->input_f16 = true;
-            ok = ok && vision_forward_device(ctx, (const float *)(dev + per * g0), gn, d_out + (size_t)(b0 + g0) * proj, normalize);
-            ctx->input_f16 = false;
-            t_enqueue += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
-        }
-        for (auto & th : pool) th.join();
-        ok = ok && hipEventRecord(hp.ev_copied[buf], hp.copy_stream) == hipSuccess;
-        ok = ok && hipEventRecord(hp.ev_consumed[buf], ctx->stream) == hipSuccess;
+        hp.pool->run(P, [&](int idx) { if (idx == 0) drive(); else packer(idx - 1); });
     }
     if (timing)
         fprintf(stderr, "encode_images_from_host: n=%d threads=%d chunk=%d | host %.2f ms (waiting for packers %.2f, enqueue H2D + forward %.2f)\n", n, P, chunk,
@@ -198,6 +304,7 @@ void free_host_pipe(clip_ctx * ctx) {
     }
     if (hp.ev_sub) (void)hipEventDestroy(hp.ev_sub);
     if (hp.copy_stream) (void)hipStreamDestroy(hp.copy_stream);
+    delete hp.pool;
     hp = HostPipe();
 }
 

@@ -62,6 +62,7 @@ struct HostPipe {
     hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // last forward reading dev_in[i]
     hipEvent_t ev_sub = nullptr;
     bool used[2] = {false, false};
+    struct PackPool * pool = nullptr;                 // persistent packer threads (host_pipeline.cpp), created on first use
 };
 
 // Pinned ring for the small per-call metadata of the text tower (sequence offsets): the upload is asynchronous and the
