@@ -329,6 +329,28 @@ def test_gemm8_ring_lengths_and_epilogues_match_the_4_wave_kernel_bitwise(L, til
     assert np.array_equal(y, y2)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_large_m_kernels_random_shapes_bitwise(L, seed):
+    """Seeded random (M, N, K): edges anywhere inside a 256 x 256 tile, 1 ... 11 K-tiles, random epilogue, bias present or not — the
+    8-wave and four-wave kernels against the 64 x 64 tile of the 4-wave kernel, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(4):
+        M = int(rng.integers(1, 1400))
+        N = int(rng.integers(4, 70)) * 16
+        K = int(rng.integers(1, 12)) * 64
+        epi = int(rng.choice([0, 1, 2, 3, 4]))
+        tname = str(rng.choice(["f16", "q4_0", "q5_1", "q8_0"]))
+        tid = ref.GGML_TYPES[tname]
+        raw = ref.quantize(tid, _weights(rng, N, K) * 3)
+        X = rng.standard_normal((M, K)).astype(np.float32)
+        bias = (rng.standard_normal(N) * 0.5).astype(np.float32) if rng.integers(0, 2) else None
+        resid = rng.standard_normal((M, N)).astype(np.float32) if epi == 4 else None
+        base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + 64064)
+        for tile in (160256, 256256, 256259):
+            y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
+            assert np.array_equal(base, y), ((M, N, K), tname, epi, tile, _diff_report(base, y))
+
+
 def test_gemm8_many_tiles_race_screen(L):
     """More workgroups than CUs, several rounds, repeated: a ring / barrier race shows up as a rare wrong tile."""
     rng = np.random.default_rng(5)
