@@ -503,10 +503,6 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
-            if (tile % 1000 == 257) {
-                if (launch_gemm8_streamk(p, epilogue, stream)) return;
-                tile = 160256;
-            }
             if (tile % 1000 == 259) {
                 launch_gemm4(p, epilogue, stream);
                 return;

@@ -279,218 +279,6 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stream-K form on 256 x 256 tiles (8 x 4 fragments per wave, two-deep ring).  One workgroup per CU; the flattened list of
-// (tile, K-tile) work units is cut into gridDim.x equal contiguous ranges, so every CU multiplies the same number of K-tiles
-// whatever the tile count (240 tiles of 160 x 256 are one round at 94 %; 150 tiles of 256 x 256 would be one round at 59 %) and
-// the CUs reach their epilogues at different times instead of in lockstep (profiles/r02_gemm8_experiments.txt, section 3).
-// A range covers [tail of a tile] [whole tiles ...] [head of a tile].  A part that does not start at k = 0 parks its fp32
-// accumulators in the split-K workspace (slot = workgroup id; agent-scope write-through stores, drained, then a per-tile ticket —
-// the hand-off of k_gemm.hip's split-K); the owner of the head (k = 0) part — which reaches it LAST in its range, when the other
-// parts, first in theirs, are long done — adds them in part order and runs the epilogue.  Deterministic (fixed order, no atomics on
-// data); NOT bit-identical to the unsplit tiles (one fp32 re-association per split tile, like split-K).
-// ---------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ void __launch_bounds__(NT8, 2) gemm8sk_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TM = 8, BM = 256, BN = 256, TN = 4;
-    constexpr int XB = BM * 128, STAGE = XB + BN * 128;
-    constexpr int NX = 4, NW = 4;                      // 32 X rows + 32 W rows per wave and K-tile
-    typedef unsigned long long u64;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int frow = lane & 15, fgrp = lane >> 4;
-    const int tiles_n = (p.W.N + BN - 1) / BN;
-    const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
-    const int T = p.W.Kpad / BK;
-    const int G = gridDim.x, cu = blockIdx.x;
-    const long U = (long)ntile * T;
-    auto ustart = [&](int c) -> long { return U * c / G; };
-    long u = ustart(cu);
-    const long uend = ustart(cu + 1);
-
-    const int sw = (fgrp ^ (lane & 7)) << 4;
-    const int lw = XB + (wn * 64 + frow) * 128;
-    const int lx = (wm * TM * 16 + frow) * 128;
-    __shared__ int sk_flag;
-
-    while (u < uend) {
-        const int tile = (int)(u / T);
-        const int k0 = (int)(u - (long)tile * T);
-        const int k1 = (long)(T - k0) < uend - u ? T : k0 + (int)(uend - u);
-        const int nkt = k1 - k0;
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;   // n fastest: consecutive work shares the activation panel
-
-        // LDS-DMA sources of this segment (recomputed per segment from an opaque lane id: nothing per-lane stays live across segments)
-        const half_t * xsrc[NX];
-        const half_t * wsrc[NW];
-        {
-            int ol = tid & 63;
-            asm volatile("" : "+v"(ol));
-            const int prow = ol >> 3;
-#pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const int tr = wave * 32 + 8 * i + prow;
-                int gm = m0 + tr;
-                gm = gm < p.M ? gm : p.M - 1;
-                xsrc[i] = p.A + (size_t)gm * p.lda + (((ol & 7) ^ (tr & 7)) << 3) + (size_t)k0 * BK;
-            }
-#pragma unroll
-            for (int j = 0; j < NW; j++) {
-                const int tr = wave * 32 + 8 * j + prow;
-                int gn = n0 + tr;
-                gn = gn < p.W.Npad ? gn : p.W.Npad - 1;
-                wsrc[j] = (const half_t *)p.W.w16 + (size_t)gn * p.W.Kpad + (((ol & 7) ^ (tr & 7)) << 3) + (size_t)k0 * BK;
-            }
-        }
-#define SK_ISSUE(st_, kt_)                                                                                        \
-    {                                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < NW; j++)                                                            \
-            GLDS16(wsrc[j] + (size_t)(kt_) * BK, smem + (st_) * STAGE + XB + (wave * 32 + 8 * j) * 128);          \
-        _Pragma("unroll") for (int i = 0; i < NX; i++)                                                            \
-            GLDS16(xsrc[i] + (size_t)(kt_) * BK, smem + (st_) * STAGE + (wave * 32 + 8 * i) * 128);               \
-    }
-#define SK_READ(st_, kk_)                                                                                         \
-    {                                                                                                             \
-        const unsigned char * sb = smem + (st_) * STAGE;                                                          \
-        const int so = (kk_) ? (sw ^ 64) : sw;                                                                    \
-        _Pragma("unroll") for (int a = 0; a < TN; a++) wf[a] = *(const h8 *)(sb + lw + a * 2048 + so);            \
-        _Pragma("unroll") for (int b = 0; b < TM; b++) xf[b] = *(const h8 *)(sb + lx + b * 2048 + so);            \
-    }
-#define SK_MFMA()                                                                                                 \
-    {                                                                                                             \
-        wait_lgkm0();                                                                                             \
-        raw_barrier();                                                                                            \
-        __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int a = 0; a < TN; a++)                                                            \
-            _Pragma("unroll") for (int b = 0; b < TM; b++)                                                        \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);             \
-        __builtin_amdgcn_s_setprio(0);                                                                            \
-        raw_barrier();                                                                                            \
-    }
-#define SK_KTILE(ST, t_)                                                                                          \
-    {                                                                                                             \
-        h8 wf[TN], xf[TM];                                                                                        \
-        if ((t_) + 1 < nkt) SK_ISSUE((ST + 1) % 2, (t_) + 1);                                                     \
-        SK_READ(ST, 0);                                                                                           \
-        SK_MFMA();                                                                                                \
-        wait_vmcnt<0>();                                                                                          \
-        SK_READ(ST, 1);                                                                                           \
-        SK_MFMA();                                                                                                \
-    }
-        f4 acc[TN][TM];
-#pragma unroll
-        for (int a = 0; a < TN; a++)
-#pragma unroll
-            for (int b = 0; b < TM; b++) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-
-        raw_barrier();                                     // the previous segment's epilogue no longer uses the LDS
-        SK_ISSUE(0, 0);
-        wait_vmcnt<0>();
-        raw_barrier();
-        if (wm == 1) raw_barrier();                        // stagger: group 1 one segment behind group 0
-        for (int t = 0; t < nkt; t += 2) {
-            SK_KTILE(0, t);
-            if (t + 1 < nkt) SK_KTILE(1, t + 1);
-        }
-        if (wm == 0) raw_barrier();
-#undef SK_KTILE
-#undef SK_MFMA
-#undef SK_READ
-#undef SK_ISSUE
-
-        const bool head = k0 == 0, whole = head && k1 == T;
-        constexpr int PER = BM * BN / 2;                   // u64 per parked tile
-        bool finish = whole;
-        if (!whole) {
-            u64 * part = (u64 *)p.sk_ws;
-            if (!head) {
-                u64 * dst = part + (size_t)cu * PER;
-                asm volatile("" : "+v"(dst));              // opaque: 64 hoisted store addresses would spill
-#pragma unroll
-                for (int a = 0; a < TN; a++)
-#pragma unroll
-                    for (int b = 0; b < TM; b++) {
-                        const float2 lo = make_float2(acc[a][b][0], acc[a][b][1]), hi = make_float2(acc[a][b][2], acc[a][b][3]);
-                        __hip_atomic_store(dst + ((a * TM + b) * 2) * NT8 + tid, __builtin_bit_cast(u64, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dst + ((a * TM + b) * 2 + 1) * NT8 + tid, __builtin_bit_cast(u64, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                // head of a split tile: the other parts belong to the next workgroups (each has it FIRST in its range)
-                long v = (long)(tile + 1) * T - 1;         // last unit of the tile
-                int c_last = (int)(v * G / U);
-                while (c_last + 1 < G && ustart(c_last + 1) <= v) c_last++;
-                while (c_last > 0 && ustart(c_last) > v) c_last--;
-                const int need = c_last - cu;
-                if (tid == 0) {
-                    int spins = 0;
-                    while ((int)__hip_atomic_load(p.sk_cnt + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spins < (1 << 22)) {
-                        __builtin_amdgcn_s_sleep(8);
-                        spins++;
-                    }
-                    sk_flag = spins < (1 << 22);
-                    __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-                }
-                __syncthreads();
-                if (sk_flag) {
-                    for (int q = 1; q <= need; q++) {
-                        const u64 * src = part + (size_t)(cu + q) * PER;
-                        asm volatile("" : "+v"(src));
-#pragma unroll
-                        for (int a = 0; a < TN; a++)
-#pragma unroll
-                            for (int b = 0; b < TM; b++) {
-                                const float2 lo = __builtin_bit_cast(float2, __hip_atomic_load(src + ((a * TM + b) * 2) * NT8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                                const float2 hi = __builtin_bit_cast(float2, __hip_atomic_load(src + ((a * TM + b) * 2 + 1) * NT8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                                acc[a][b] += (f4){lo.x, lo.y, hi.x, hi.y};
-                                if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 8 loads in flight, not 64: registers
-                            }
-                    }
-                }
-                finish = true;                             // (a timed-out wait still writes: bounded spin, never a hang)
-            }
-        }
-        if (finish) {
-            const int nb = n0 + wn * 64, mb = m0 + wm * TM * 16;
-            bool done = false;
-            if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
-                if (nb + 64 <= p.W.N && (p.ldc & 7) == 0) {
-                    gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, (half_t *)smem + wave * (TM * 16) * 68, lane);
-                    done = true;
-                }
-            }
-            if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp);
-        }
-        u += nkt;
-    }
-}
-
-template <int EPI>
-void launch8sk(const GemmParams & p, hipStream_t stream) {
-    constexpr size_t smem = (size_t)8 * (8 * 16) * 68 * sizeof(half_t);     // fp16 epilogue staging (139 KB) > the 2 x 64 KB ring
-    static unsigned long long lds_ok = 0;
-    opt_in_dynamic_lds(gemm8sk_kernel<EPI>, smem, lds_ok);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
-        n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int ntile = ((p.M + 255) / 256) * ((p.W.N + 255) / 256);
-    const long units = (long)ntile * (p.W.Kpad / BK);
-    int grid = n_cu;
-    if ((long)grid > units) grid = (int)units;
-    if ((size_t)grid * 65536 > p.sk_ws_floats) grid = (int)(p.sk_ws_floats / 65536);    // one parked 256 x 256 fp32 tile per workgroup
-    hipLaunchKernelGGL((gemm8sk_kernel<EPI>), dim3(grid), dim3(NT8), smem, stream, p);
-}
-
 template <int TM, int EPI>
 void launch8(const GemmParams & p, hipStream_t stream) {
     constexpr int BM = 32 * TM;
@@ -557,22 +345,6 @@ void launch_dequant_wt(const DequantJobs & jobs, hipStream_t stream) {
 }
 
 }  // namespace
-
-// stream-K form (256 x 256 tiles, one workgroup per CU); needs the split-K workspace (>= one 256 KB slot per workgroup) and counters
-bool launch_gemm8_streamk(const GemmParams & p, int epilogue, hipStream_t stream) {
-    const int ntile = ((p.M + 255) / 256) * ((p.W.N + 255) / 256);
-    if (!p.sk_ws || !p.sk_cnt || ntile > p.sk_cnt_n || p.sk_ws_floats < (size_t)8 * 65536) return false;
-    switch (epilogue) {
-    case EPI_F32: launch8sk<EPI_F32>(p, stream); break;
-    case EPI_F16: launch8sk<EPI_F16>(p, stream); break;
-    case EPI_GELU_F16: launch8sk<EPI_GELU_F16>(p, stream); break;
-    case EPI_QGELU_F16: launch8sk<EPI_QGELU_F16>(p, stream); break;
-    case EPI_RESID_F32: launch8sk<EPI_RESID_F32>(p, stream); break;
-    case EPI_PATCH_F32: launch8sk<EPI_PATCH_F32>(p, stream); break;
-    default: return false;
-    }
-    return true;
-}
 
 // tm: fragments of 16 rows per wave in M (tile = 32 tm x 256): 3, 4, 5 or 8
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream) {

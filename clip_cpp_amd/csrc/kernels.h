@@ -88,13 +88,12 @@ struct GemmParams {
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
 int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
 // the shape runs on a large-M kernel that multiplies an fp16 W panel (k_gemm8.hip / k_gemm4.hip).  BN codes: 256 plain 8-wave tile
-// (BM 96 / 128 / 160 / 256), 257 stream-K form of the 8-wave 256 x 256 tile, 258 the 8-wave 256 x 256 tile on the rows that fill whole
-// rounds of 256 workgroups + a second launch for the rest, 259 the 4-wave 256 x 256 tile (k_gemm4.hip), 260 = 259 with the whole-rounds split
-inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return bn >= 256 && bn <= 260; }
+// (BM 96 / 128 / 160 / 256), 258 the 8-wave 256 x 256 tile on the rows that fill whole rounds of 256 workgroups + a second launch for the
+// rest, 259 the 4-wave 256 x 256 tile (k_gemm4.hip), 260 = 259 with the whole-rounds split
+inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return bn == 256 || (bn >= 258 && bn <= 260); }
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);
-bool launch_gemm8_streamk(const GemmParams & p, int epilogue, hipStream_t stream);   // false: workspace missing / too small
 // k_gemm4.hip: 4 waves x (128 x 128) on 256 x 256 tiles, accumulators in AGPRs, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel)
 void launch_gemm4(const GemmParams & p, int epilogue, hipStream_t stream);
 // dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)

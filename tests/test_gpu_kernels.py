@@ -381,27 +381,6 @@ def test_gemm8_whole_rounds_split_is_bitwise_identical(L, tname, epi):
         assert np.array_equal(base, y), (tile, np.abs(base - y).max())
 
 
-@pytest.mark.parametrize("M,N,K", [(333, 576, 192), (200, 256, 3072), (4000, 1024, 768), (2051, 768, 64), (700, 300, 1024), (12800, 768, 3072)])
-@pytest.mark.parametrize("tname,epi", [("f16", 0), ("q4_0", 4), ("q5_1", 1), ("q8_0", 3)])
-def test_gemm8_stream_k_is_deterministic_and_matches_unsplit(L, M, N, K, tname, epi):
-    """Stream-K form of the 256 x 256 tile (k_gemm8.hip, gemm8sk_kernel; tile code 256257): the (tile, K-tile) units are cut into one
-    equal range per CU, split tiles are finished by the owner of their k = 0 part adding the parked partial sums in part order.
-    Same bits run to run; equal to the unsplit kernel up to one fp32 re-association per split tile.  Shapes: fewer units than CUs,
-    one tile spread over many CUs (200 x 256, K = 3072), ranges of several whole tiles, M / N edges, every epilogue family."""
-    rng = np.random.default_rng(M + K)
-    tid = ref.GGML_TYPES[tname]
-    raw = ref.quantize(tid, _weights(rng, N, K) * 3)
-    X = rng.standard_normal((M, K)).astype(np.float32)
-    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
-    resid = rng.standard_normal((M, N)).astype(np.float32)
-    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + 128128)
-    y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=256257)
-    assert np.all(np.isfinite(y))
-    assert np.abs(y - base).max() <= 2e-3 * max(1.0, np.abs(base).max()), np.abs(y - base).max()
-    for _ in range(3):
-        assert np.array_equal(run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=256257), y)
-
-
 def run_skinny(L, tid, raw, N, K, X, bias=None, resid=None, ln=None, epi=0, qcols=0, qscale=1.0, stats=None):
     M = X.shape[0]
     y = np.full((M, N), np.nan, dtype=np.float32)
