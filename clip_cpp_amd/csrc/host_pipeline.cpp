@@ -362,6 +362,7 @@ struct MultiCtx {
     std::vector<size_t> send_floats, recv_floats;
     Rccl rccl;
     bool use_rccl = true;
+    bool collective = false;              // the all-gather runs (G > 1, or G == 1 with CLIP_AMD_MULTI_FORCE_RCCL=1)
 };
 
 clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
@@ -389,7 +390,11 @@ clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
     }
     mc->send.assign(n_devices, nullptr); mc->recv.assign(n_devices, nullptr);
     mc->send_floats.assign(n_devices, 0); mc->recv_floats.assign(n_devices, 0);
-    if (n_devices > 1) {
+    // CLIP_AMD_MULTI_FORCE_RCCL=1 (test aid for 1-GPU machines): a single replica still goes through ncclCommInitAll and a one-rank
+    // grouped ncclAllGather, so the dlopen binding, the enum values and the call sequence run on hardware
+    const char * force = getenv("CLIP_AMD_MULTI_FORCE_RCCL");
+    mc->collective = n_devices > 1 || (force && force[0] == '1');
+    if (mc->collective) {
         const char * e = getenv("CLIP_AMD_MULTI_NO_RCCL");   // debugging aid: G device-to-host copies into disjoint slices instead of the all-gather
         mc->use_rccl = !(e && e[0] == '1') && !oversub;
         if (mc->use_rccl) {
@@ -456,7 +461,7 @@ bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, i
     }
     for (int g = 0; g < G; g++) if (!okv[g]) { fprintf(stderr, "clip_image_batch_encode: shard %d failed\n", g); return false; }
     bool ok = true;
-    if (G > 1 && mc->use_rccl) {
+    if (mc->collective && mc->use_rccl) {
         // ONE all-gather of the final embeddings: [per_dev][proj] per device -> [G * per_dev][proj] on every device
         ok = mc->rccl.GroupStart() == 0;
         for (int g = 0; g < G && ok; g++)

@@ -50,6 +50,32 @@ def test_sharded_batch_encode_matches_single_context(clip_lib, fixture_cache, G,
 
 
 @pytest.mark.gpu
+def test_rccl_binding_runs_on_one_device(clip_lib, fixture_cache, monkeypatch):
+    """The RCCL calls themselves — dlopen of librccl, ncclCommInitAll, grouped ncclAllGather with ncclFloat32, ncclCommDestroy — on ONE
+    device (CLIP_AMD_MULTI_FORCE_RCCL=1: a single replica still goes through the collective): the binding, the enum value and the call
+    sequence of the multi-GPU path execute on hardware even where a second GPU is not available."""
+    if clip_lib.device_count() < 1:
+        pytest.fail("GPU tier needs a HIP device")
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("CLIP_AMD_MULTI_FORCE_RCCL", "1")
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=False, vision=True)
+    single = clip_lib.Clip(p, device=0)
+    multi = clip_lib.Clip(p, n_devices=1)
+    for B in (2, 37, 300):
+        imgs = fixtures.synthetic_images(B, 32, seed=B)
+        want = single.encode_images(imgs)
+        assert np.array_equal(multi.encode_images(imgs), want)
+        ptr = clip_lib.lib().clip_amd_gathered_embeddings(multi.ctx, 0)        # the all-gather's receive buffer
+        assert ptr
+        t = torch.empty((B, 32), dtype=torch.float32, device="cuda:0")
+        assert C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), B * 32 * 4, 3) == 0
+        assert np.array_equal(t.cpu().numpy(), want)
+    multi.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_rccl_all_gather_path_with_two_devices(clip_lib, fixture_cache):
     if clip_lib.device_count() < 2:
         pytest.skip("needs >= 2 visible HIP devices (the 1-GPU box runs the over-subscribed form above)")
