@@ -145,8 +145,14 @@ def main():
     if not torch.cuda.is_available() or clip_cpp_amd.device_count() < 1:
         raise SystemExit("bench.py: no HIP device — the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if N > 1:
+    # BENCH_FORCE_DIST=1: a single rank still initialises the RCCL process group and runs the all-gather / barrier / max-reduce of the
+    # N > 1 path (one-rank collectives), so that path executes on a 1-GPU box (tests/test_bench_contract.py)
+    use_dist = N > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     cache = os.environ.get("CLIP_AMD_FIXTURE_CACHE", "/tmp/clip_amd_fixtures")
@@ -179,7 +185,7 @@ def main():
     offsets = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
     d_ids = torch.from_numpy(flat).cuda()
     emb = torch.empty((batch + n_texts, proj), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((N * (batch + n_texts), proj), dtype=torch.float32, device="cuda") if N > 1 else None
+    gathered = torch.empty((N * (batch + n_texts), proj), dtype=torch.float32, device="cuda") if use_dist else None
     img_out = emb[:batch]
     txt_out = emb[batch:]
 
@@ -194,11 +200,11 @@ def main():
 
     def step():
         local_step()
-        if N > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, emb)   # the single RCCL all-gather of the final embeddings
 
     def sync():
-        if N > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -215,7 +221,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if N > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -390,7 +396,7 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
             with open(args.json_out, "w") as f:
                 f.write(line + "\n")
-    if N > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -36,6 +36,21 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "traffic" in rf and "traffic_note" in rf
 
 
+def test_bench_collective_path_runs_with_one_rank():
+    """The N > 1 code path of bench.py — RCCL process group on the dedicated stream, all_gather_into_tensor of the embeddings, barrier,
+    max-reduce of the time — executed with ONE rank (BENCH_FORCE_DIST=1): the 1-GPU box cannot run two ranks, but the calls, their
+    stream ordering with the HIP kernels and the gathered buffer are exercised on hardware."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat", "0.2", "--model", "tiny",
+                        "--ftype", "q4_0", "--batch", "16", "--no-cpu-baseline", "--no-roofline", "--no-host-api"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+
+
 def test_graft_entry_smoke_runs():
     r = subprocess.run([sys.executable, "__graft_entry__.py", "--smoke"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
