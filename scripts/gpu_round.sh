@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r02}
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-echo "== GPU tests" ; timeout 1500 python -m pytest tests/ -m gpu -q 2>&1 | tail -6 | tee gpurun_out/${TAG}_tests.log
+echo "== GPU tests" ; timeout 1500 python -m pytest tests/ -m gpu -q 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" | tail -12 | tee gpurun_out/${TAG}_tests.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
 echo "== bench" ; timeout 900 python bench.py --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -2 | cut -c1-4000 | tee gpurun_out/${TAG}_bench.log
 echo "== rocprof kernel trace (default config)" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "$R/bench.py" --steps 10 --warmup 3 --preheat 0.3 --no-cpu-baseline --no-roofline --no-host-api > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
