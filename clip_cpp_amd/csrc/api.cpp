@@ -710,7 +710,7 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     return ms < 0 ? -4.f : ms * 1000.f / iters;
 }
 
-// Small-M kernel (k_skinny.hip) on host data: y[M][N] = epilogue(A . W^T + bias), M <= 64.  ln_w != NULL: A = LayerNorm(x) fused in
+// Small-M kernel (k_skinny.hip) on host data: y[M][N] = epilogue(A . W^T + bias), M <= SKINNY_MAX_ROWS.  ln_w != NULL: A = LayerNorm(x) fused in
 // the kernel (row statistics via launch_row_stats, as forward.cpp does for the first layer); else A = fp16(x).
 // epilogue: 0 f32, 1 f16 (+ qcols / qscale), 2 gelu, 3 quick-gelu, 4 residual (also returns the partial row statistics it leaves:
 // stats_out [N/16][128][2], may be NULL).  Returns 0, or -5 when the combination is not covered by the skinny path.
@@ -723,11 +723,11 @@ int clip_amd_test_skinny(int type, const void * w_raw, int64_t N, int64_t K, con
     if (!repack_for_test(type, w_raw, N, K, W, &wbase)) return -2;
     const int Kpad = W.Kpad;
     DBuf dx32((size_t)M * K * 4), dx16((size_t)(M + 1) * Kpad * 2), dbias((size_t)N * 4), dout((size_t)M * N * 4), dout32((size_t)M * N * 4), dlw((size_t)K * 4), dlb((size_t)K * 4),
-        dst((size_t)2 * 128 * 128 * 8);
+        dst((size_t)2 * SKINNY_MAX_ROWS * 128 * 8);
     hipStream_t s = nullptr;
     (void)hipMemcpy(dx32.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice);
     if (bias) (void)hipMemcpy(dbias.p, bias, (size_t)N * 4, hipMemcpyHostToDevice);
-    (void)hipMemset(dst.p, 0, (size_t)2 * 128 * 128 * 8);
+    (void)hipMemset(dst.p, 0, (size_t)2 * SKINNY_MAX_ROWS * 128 * 8);
     SkinnyParams p;
     p.M = (int)M; p.W = W; p.bias = bias ? (const float *)dbias.p : nullptr; p.ldc = (int)N; p.qcols = qcols; p.qscale = qscale;
     if (ln_w) {
@@ -750,7 +750,7 @@ int clip_amd_test_skinny(int type, const void * w_raw, int64_t N, int64_t K, con
         epi = EPI_RESID_F32;
         (void)hipMemcpy(dout32.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice);
         p.out = dout32.p; p.resid = (const float *)dout32.p;
-        p.stats_out = (float2 *)dst.p + 128 * 128;
+        p.stats_out = (float2 *)dst.p + (size_t)SKINNY_MAX_ROWS * 128;
         break;
     default: (void)hipFree(wbase); return -3;
     }
@@ -763,7 +763,7 @@ int clip_amd_test_skinny(int type, const void * w_raw, int64_t N, int64_t K, con
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = -4;
         else {
             (void)hipMemcpy(y, dout32.p, (size_t)M * N * 4, hipMemcpyDeviceToHost);
-            if (stats_out && epi == EPI_RESID_F32) (void)hipMemcpy(stats_out, (float2 *)dst.p + 128 * 128, (size_t)128 * 128 * 8, hipMemcpyDeviceToHost);
+            if (stats_out && epi == EPI_RESID_F32) (void)hipMemcpy(stats_out, (float2 *)dst.p + (size_t)SKINNY_MAX_ROWS * 128, (size_t)128 * 128 * 8, hipMemcpyDeviceToHost);   // (rows 0..127)
         }
     }
     (void)hipFree(wbase);

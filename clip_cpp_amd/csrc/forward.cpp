@@ -10,6 +10,7 @@
 // Residual stream: f32 [rows][h] in HBM for the whole pass (as in ggml).  7 launches per layer.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "model.h"
@@ -82,6 +83,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
     char fam[96];
     if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
     else if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
+    else if (gemm_tile_is_ring(tile)) snprintf(fam, sizeof fam, "gemm_ring_kernel<%d,%d,4,%d,%d>/%s", wt, tile % 1000, tile % 1000 >= 128 ? 4 : 2, epi, what);
     else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", wt, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
     ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
     launch_gemm(p, epi, 0, ctx->stream);
@@ -144,8 +146,18 @@ void skinny(clip_ctx * ctx, const char * what, const SkinnyParams & p, int epi) 
     launch_skinny(p, epi, ctx->stream);
 }
 
+int skinny_row_limit() {     // rows up to which the small-M kernels carry the layers (CLIP_AMD_SKINNY_ROWS: tuning override)
+    static int lim = -1;
+    if (lim < 0) {
+        const char * e = getenv("CLIP_AMD_SKINNY_ROWS");
+        lim = e ? atoi(e) : 64;
+        if (lim > SKINNY_MAX_ROWS) lim = SKINNY_MAX_ROWS;
+    }
+    return lim;
+}
+
 bool layers_fit_skinny(const DevTower & tw, int rows, int h, int ff) {
-    if (!skinny_enabled() || rows <= 0 || rows > 64 || h > 2048 || h % 16 || h / 16 > 128 || tw.layers.empty()) return false;
+    if (!skinny_enabled() || rows <= 0 || rows > skinny_row_limit() || h > 2048 || h % 16 || h / 16 > 128 || tw.layers.empty()) return false;
     const DevLayer & l = tw.layers[0];
     return l.qkv.K == l.qkv.Kpad && l.ff1.K == l.ff1.Kpad && l.o.N == h && l.ff2.N == h && l.ff1.N == ff;
 }
@@ -157,7 +169,7 @@ bool run_layers_skinny(clip_ctx * ctx, const DevTower & tw, int rows, int h, int
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
-    float2 * stA = ctx->sk_stats, * stB = ctx->sk_stats + 128 * 128;
+    float2 * stA = ctx->sk_stats, * stB = ctx->sk_stats + (size_t)SKINNY_MAX_ROWS * 128;
     int slotsA = 1;
     for (const DevLayer & l : tw.layers) {
         SkinnyParams q;   // LN1 + q/k/v projection (+ Q scale after the bias, clip.cpp:1363)

@@ -45,18 +45,23 @@ template <> struct WFrag<W_Q5_0> { uint32_t q, h; half_t d; };
 template <> struct WFrag<W_Q5_1> { uint32_t q, h; h2 dm; };
 template <> struct WFrag<W_Q8_0> { uint32_t q, q1; half_t d; };
 
+// One pair of weights (output word s = 0..3 of the fragment: elements 2s, 2s+1 of the lane's 8) — the unit the ring kernel
+// (k_gemm_ring.hip) slots between its MFMAs; dequant_wfrag below is the four of them, so every kernel computes the same bits.
+// hb: fifth-bit word of the lane's k-group (dequant_hbits), q5 only.
 template <int WT>
-__device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
-    uint32_t o[4] = {0, 0, 0, 0};
-    if constexpr (WT == W_F16) return __builtin_bit_cast(h8, (u32x4){f.q, 0u, 0u, 0u});
-    else
-    if constexpr (WT == W_Q8_0) {
+__device__ __forceinline__ uint32_t dequant_hbits(const WFrag<WT> & f, int g) {
+    if constexpr (WT == W_Q5_0 || WT == W_Q5_1) return (uint32_t)(((uint64_t)f.h << 4) >> (4 * g));   // pair bits of word g at 4+s / 20+s
+    else return 0u;
+}
+template <int WT>
+__device__ __forceinline__ uint32_t dequant_wpair(const WFrag<WT> & f, uint32_t hb, int s) {
+    if constexpr (WT == W_F16) return f.q;
+    else if constexpr (WT == W_Q8_0) {
         const h2 scale = (h2){f.d, f.d};
         const h2 sub = splat(1152.0f);
-        o[0] = h2u((u2h((f.q & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-        o[1] = h2u((u2h(((f.q >> 8) & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-        o[2] = h2u((u2h((f.q1 & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
-        o[3] = h2u((u2h(((f.q1 >> 8) & 0x00FF00FFu) | 0x64006400u) - sub) * scale);
+        const uint32_t w = s < 2 ? f.q : f.q1;
+        const uint32_t u = ((s & 1) ? (w >> 8) : w) & 0x00FF00FFu;
+        return h2u((u2h(u | 0x64006400u) - sub) * scale);
     } else {
         h2 scale, sub, add;
         if constexpr (WT == W_Q4_0) { scale = (h2){f.d, f.d}; sub = splat(1032.0f); }
@@ -66,19 +71,22 @@ __device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
             add = (h2){f.dm[1], f.dm[1]};
             sub = splat(1024.0f);
         }
-        uint32_t hb = 0;
-        if constexpr (WT == W_Q5_0 || WT == W_Q5_1) hb = (uint32_t)(((uint64_t)f.h << 4) >> (4 * g));  // pair bits of word g at 4+s / 20+s
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            uint32_t u = ((f.q >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
-            if constexpr (WT == W_Q5_0 || WT == W_Q5_1) u |= (hb >> s) & 0x00100010u;
-            h2 v = u2h(u) - sub;  // exact small integer
-            if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
-            else v = v * scale;
-            o[s] = h2u(v);
-        }
+        uint32_t u = ((f.q >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
+        if constexpr (WT == W_Q5_0 || WT == W_Q5_1) u |= (hb >> s) & 0x00100010u;
+        h2 v = u2h(u) - sub;  // exact small integer
+        if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
+        else v = v * scale;
+        return h2u(v);
     }
-    return __builtin_bit_cast(h8, (u32x4){o[0], o[1], o[2], o[3]});
+}
+
+template <int WT>
+__device__ __forceinline__ h8 dequant_wfrag(const WFrag<WT> & f, int g) {
+    if constexpr (WT == W_F16) return __builtin_bit_cast(h8, (u32x4){f.q, 0u, 0u, 0u});
+    else {
+        const uint32_t hb = dequant_hbits<WT>(f, g);
+        return __builtin_bit_cast(h8, (u32x4){dequant_wpair<WT>(f, hb, 0), dequant_wpair<WT>(f, hb, 1), dequant_wpair<WT>(f, hb, 2), dequant_wpair<WT>(f, hb, 3)});
+    }
 }
 
 // One whole 32-weight block per thread (LDS-staged path): the 4 (q8_0: 8) packed words + fifth bits + scale.
@@ -188,6 +196,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
             } else if constexpr (EPI == EPI_RESID_F32) {
                 const f4 r = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
                 *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = r + v;
+            } else if constexpr (EPI == EPI_PATCH_F32) {
+                const int img = m / p.Np, pp = m % p.Np;
+                const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
+                *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
+            } else {
+                if constexpr (EPI == EPI_F16) {
+                    if (n < p.qcols) v = v * p.qscale;
+                } else if constexpr (EPI == EPI_GELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
+                } else if constexpr (EPI == EPI_QGELU_F16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
+                }
+                const h2 lo = (h2){(_Float16)v[0], (_Float16)v[1]};
+                const h2 hi = (h2){(_Float16)v[2], (_Float16)v[3]};
+                *(uint2 *)((half_t *)p.out + (size_t)m * p.ldc + n) = make_uint2(h2u(lo), h2u(hi));
+            }
+        }
+    }
+}
+
+// ---- the same epilogue with its operands already in registers (k_gemm_ring.hip): the bias vectors — and, for the residual epilogue,
+// the residual fragments — were requested before the K loop, so the tail of a workgroup that has its CU to itself does not wait out
+// a memory round trip per strip (measured there: 7 us of a 60 us kernel at 64 x 256 tiles).  Same expressions, same rounding.
+template <int EPI, int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc)[TN][TM], const f4 (&biasv)[TN], const f4 (&rpre)[TN][TM],
+                                                  int nbase, int mbase, int frow, int fgrp) {
+    const int N = p.W.N;
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        const int n = nbase + a * 16 + fgrp * 4;
+        if (n >= N) continue;
+        const f4 bias = biasv[a];
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            const int m = mbase + b * 16 + frow;
+            if (m >= p.M) continue;
+            f4 v = acc[a][b] + bias;
+            if constexpr (EPI == EPI_F32) {
+                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = rpre[a][b] + v;
             } else if constexpr (EPI == EPI_PATCH_F32) {
                 const int img = m / p.Np, pp = m % p.Np;
                 const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);

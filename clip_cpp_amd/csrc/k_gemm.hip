@@ -393,6 +393,22 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 int pick_tile(int M, int N, int Kpad, bool quantised) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
+    if (M <= 4096) {
+        // mid-M (a few hundred to a few thousand rows: batches of 2-64 ViT-B/32 images, batches of texts, single ViT-L/14 images): the
+        // ring kernel of k_gemm_ring.hip where the sweep of profiles/r02_ring_sweep_*.txt (M = 130 ... 3200 x the model widths, q4_0 and
+        // f16, every tile form) has it ahead: short K — 64 x 64 tiles while they number <= ~260, else 64 x 128 up to ~500 tiles;
+        // long K (32+ K-tiles) — fp16 weights on 64 x 64 tiles, block-quantised weights on 64 x 128 from ~1000 rows (below that the
+        // split-K form of the two-buffer kernel is level or ahead).  Gains there: 10-50 % per GEMM; outside, the kernels below.
+        const int tm = (M + 63) / 64, t64 = tm * ((N + 63) / 64), t128 = tm * ((N + 127) / 128), nk = Kpad / BK;
+        if (nk < 32) {
+            if (t64 <= 260) return 65064;
+            if (t128 <= 500) return 65128;
+        } else if (!quantised) {
+            if (t64 <= 340) return 65064;
+        } else if (M >= 1024 && t128 <= 340) {
+            return 65128;
+        }
+    }
     if (wgs(128, 128) < 100) return wgs(64, 128) >= 256 ? 64128 : 64064;
     // large M: the 8-wave 160 x 256 kernel (k_gemm8.hip), one workgroup per CU -> rounds of 256 tiles.  Its K loop is the faster
     // one (3-stage ring, ping-pong: ~69 % of the MFMA peak in the loop) but with one workgroup per CU nothing overlaps a tile's
@@ -455,6 +471,13 @@ int pick_ksplit(int tiles, int nk) {
     return ks < 1 ? 1 : ks > 16 ? 16 : ks;
 }
 
+// Split-K for the ring kernel (fitted to profiles/r02_ring_sweep_*.txt): only the long-K GEMMs (FFN down: 32+ K-tiles) with few tiles.
+int pick_ksplit_ring(int tiles, int nk, bool quantised) {
+    if (nk < 32) return 1;
+    if (quantised) return tiles <= 160 ? 3 : 1;
+    return tiles <= 110 ? 2 : 1;
+}
+
 void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stream) {
     if (p0.M <= 0) return;
     GemmParams p = p0;
@@ -512,14 +535,21 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         }
         tile = 160128;   // no panel available: the fused 4-wave kernel
     }
-    const int bm = tile / 1000, bn = tile % 1000;
+    const bool ring = gemm_tile_is_ring(tile);         // k_gemm_ring.hip: 64-row tiles, BN in {64, 128}
+    const int bm = ring ? 64 : tile / 1000;
+    int bn = tile % 1000;
+    if (ring) bn = bn >= 128 ? 128 : 64;
     const int tiles = ((p.M + bm - 1) / bm) * ((p.W.N + bn - 1) / bn), nk = p.W.Kpad / BK;
-    if (heuristic) ksplit = pick_ksplit(tiles, nk);
+    if (heuristic) ksplit = ring ? pick_ksplit_ring(tiles, nk, p.W.wtype != W_F16) : pick_ksplit(tiles, nk);
     if (ksplit < 1) ksplit = 1;
     if (bm != 64 || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n) ksplit = 1;
     if (ksplit > nk / 2) ksplit = nk / 2 > 0 ? nk / 2 : 1;
     while (ksplit > 1 && (size_t)tiles * ksplit * bm * bn > p.sk_ws_floats) ksplit--;
     p.ksplit = ksplit;
+    if (ring) {
+        launch_gemm_ring(p, epilogue, bn, stream);
+        return;
+    }
     switch (p.W.wtype) {
     case W_F16: launch_gemm_wt0(p, epilogue, tile, stream); break;
     case W_Q4_0: launch_gemm_wt1(p, epilogue, tile, stream); break;

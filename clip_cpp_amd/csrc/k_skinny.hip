@@ -44,8 +44,9 @@ __device__ __forceinline__ h8 normalise8(const f4 lo, const f4 hi, float mean, f
 
 template <int WT, int MF, int NW, int EPI, bool LNA>
 __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
-    constexpr int CH = LNA ? 3 : 4;                   // k-blocks per chunk; two chunks in flight = 6 (f32 rows) / 8 (fp16 rows) k-blocks
-                                                      // of loads per lane: the whole K range of a wave at K = 768 / 1024
+    constexpr int CH = LNA ? 3 : (MF == 1 ? 6 : 4);   // k-blocks per chunk; two chunks in flight = 6 (f32 rows) / 8-12 (fp16 rows) k-blocks
+                                                      // of loads per lane: the whole K range of a wave at K = 768 / 1024 (and at K = 3072
+                                                      // with 8 waves and one fragment row)
     __shared__ f4 red[NW * MF * 64];
     __shared__ float2 lnst[LNA ? 128 : 1];
     __shared__ float lng[LNA ? 2048 : 1], lnb[LNA ? 2048 : 1];
@@ -55,12 +56,13 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fgrp = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int m_base = blockIdx.y * (MF * 16);        // grid.y splits the rows: with MF = 1 a workgroup owns ONE 16 x 16 output fragment
     const int nkb = p.W.Kpad / 32;
     const int kb_lo = wave * nkb / NW, kb_hi = (wave + 1) * nkb / NW;
 
     int mrow[MF];
 #pragma unroll
-    for (int b = 0; b < MF; b++) { const int m = b * 16 + frow; mrow[b] = m < p.M ? m : p.M - 1; }
+    for (int b = 0; b < MF; b++) { const int m = m_base + b * 16 + frow; mrow[b] = m < p.M ? m : p.M - 1; }
 
     // ---- operand loaders (one k-block = one 16 x 32 weight fragment + MF 16 x 32 activation fragments)
     struct WReg { WFrag<WT> q; h8 h; };
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
     static_assert(MF <= NW, "each wave finalises at most one fragment row");
     f4 bias_pre = (f4){0.f, 0.f, 0.f, 0.f}, resid_pre = (f4){0.f, 0.f, 0.f, 0.f};
     {
-        const int n = n0 + fgrp * 4, m = wave * 16 + frow;
+        const int n = n0 + fgrp * 4, m = m_base + wave * 16 + frow;
         if (EPI != EPI_PATCH_F32 && p.bias && n < p.W.N) bias_pre = *(const f4 *)(p.bias + n);
         if constexpr (EPI == EPI_RESID_F32) {
             if (wave < MF && m < p.M && n < p.W.N) resid_pre = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
@@ -125,8 +127,9 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         // per round), then a butterfly over the TPR lanes: a fixed summation tree (bit-reproducible), one memory round trip
         {
             constexpr int TPR = (NW * 64) / (MF * 16);
-            const int r = tid / TPR, sub = tid % TPR;
-            const float2 * row = p.stats_in + (size_t)(r < p.M ? r : p.M - 1) * p.stats_cap;
+            const int r = tid / TPR, sub = tid % TPR;          // r: row inside this workgroup's block of MF * 16 rows
+            const int gr = m_base + r;
+            const float2 * row = p.stats_in + (size_t)(gr < p.M ? gr : p.M - 1) * p.stats_cap;
             float s1 = 0.f, s2 = 0.f;
             for (int base = 0; base < p.stats_slots; base += TPR * 16) {
                 float2 v[16];
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
             }
 #pragma unroll
             for (int o = TPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if (sub == 0 && r < p.M) {
+            if (sub == 0) {                                   // (rows past M hold the statistics of the clamped row M - 1, like their data)
                 const float mu = s1 / (float)p.W.K;
                 float var = s2 / (float)p.W.K - mu * mu;
                 var = var > 0.f ? var : 0.f;
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int b = 0; b < MF; b++) { const float2 st = lnst[mrow[b]]; mean[b] = st.x; rstd[b] = st.y; }
+        for (int b = 0; b < MF; b++) { const float2 st = lnst[b * 16 + frow]; mean[b] = st.x; rstd[b] = st.y; }
     }
 
     f4 acc[MF];
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         f4 v = red[b * 64 + lane];
         for (int w = 1; w < NW; w++) v = v + red[(w * MF + b) * 64 + lane];
         const int n = n0 + fgrp * 4;
-        const int m = b * 16 + frow;
+        const int m = m_base + b * 16 + frow;
         const bool ok = m < p.M && n < p.W.N;
         v = v + (b == wave ? bias_pre : (f4){0.f, 0.f, 0.f, 0.f});   // (MF <= NW: a wave finalises at most the one fragment row b == wave)
         if constexpr (EPI == EPI_F32) {
@@ -234,7 +237,9 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
 
 template <int WT, int MF, int NW, int EPI, bool LNA>
 void launch_sk(const SkinnyParams & p, hipStream_t stream) {
-    hipLaunchKernelGGL((skinny_kernel<WT, MF, NW, EPI, LNA>), dim3((p.W.N + 15) / 16), dim3(NW * 64), 0, stream, p);
+    // grid.x = column groups (a multiple of 8 for every CLIP width: the row blocks of one column group land on one XCD and share its
+    // L2 copy of the weight slab), grid.y = row blocks
+    hipLaunchKernelGGL((skinny_kernel<WT, MF, NW, EPI, LNA>), dim3((p.W.N + 15) / 16, (p.M + MF * 16 - 1) / (MF * 16)), dim3(NW * 64), 0, stream, p);
 }
 
 template <int WT, int MF>
@@ -272,7 +277,9 @@ void launch_sk_epi(const SkinnyParams & p, int epi, hipStream_t stream) {
 #define CLIPAMD_SCAT2(a, b) a##b
 #define CLIPAMD_SCAT(a, b) CLIPAMD_SCAT2(a, b)
 void CLIPAMD_SCAT(launch_skinny_wt, CLIPAMD_SKINNY_WT)(const SkinnyParams & p, int epilogue, hipStream_t stream) {
-    launch_sk_epi<CLIPAMD_SKINNY_WT, 4>(p, epilogue, stream);
+    // one 16-row fragment per workgroup: N / 16 x ceil(M / 16) workgroups (192-768 for one ViT-B/32 image instead of 48-192), each a
+    // single memory round trip + <= 12 MFMAs per wave; weights are re-read by the row blocks from L2
+    launch_sk_epi<CLIPAMD_SKINNY_WT, 1>(p, epilogue, stream);
 }
 #else
 void launch_skinny_wt0(const SkinnyParams &, int, hipStream_t);
@@ -284,7 +291,7 @@ void launch_skinny_wt5(const SkinnyParams &, int, hipStream_t);
 
 // which (epilogue, operand) combinations the skinny path covers; everything else stays on launch_gemm
 bool skinny_supported(const SkinnyParams & p, int epilogue) {
-    if (p.M <= 0 || p.M > 64 || p.W.N % 4 || p.ldc % 4) return false;
+    if (p.M <= 0 || p.M > SKINNY_MAX_ROWS || p.W.N % 4 || p.ldc % 4) return false;
     if (p.x32) {
         if (epilogue != EPI_F16 && epilogue != EPI_GELU_F16 && epilogue != EPI_QGELU_F16) return false;
         return p.W.K == p.W.Kpad && p.W.K <= 2048 && p.ldx % 4 == 0 && p.ln_w && p.ln_b && p.stats_in && p.stats_slots > 0;

@@ -83,14 +83,21 @@ struct GemmParams {
     int debug = 0;   // ablation switches, honoured only by -DCLIPAMD_ABLATION tuning builds (scripts/build_variant.sh): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
 };
 
-// tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64;
+// tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64 / 65;
+// BM = 65: the ring kernel of k_gemm_ring.hip on 64-row tiles, BN in {64,128};
 // BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
 int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
 // the shape runs on a large-M kernel that multiplies an fp16 W panel (k_gemm8.hip / k_gemm4.hip).  BN codes: 256 plain 8-wave tile
 // (BM 96 / 128 / 160 / 256), 258 the 8-wave 256 x 256 tile on the rows that fill whole rounds of 256 workgroups + a second launch for the
 // rest, 259 the 4-wave 256 x 256 tile (k_gemm4.hip), 260 = 259 with the whole-rounds split
-inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return bn == 256 || (bn >= 258 && bn <= 260); }
+inline bool gemm_tile_is_ring(int tile) { return (tile % 1000000) / 1000 == 65; }   // k_gemm_ring.hip (BM code 65)
+inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return !gemm_tile_is_ring(tile) && (bn == 256 || (bn >= 258 && bn <= 260)); }
+
+// k_gemm_ring.hip: mid-M GEMM (64 activation rows x bn weight rows per workgroup, bn in {64, 128}; a 3-4 stage LDS ring of K-tiles
+// filled by LDS-DMA only, block-quantised weights staged raw and dequantised per MFMA fragment; split-K as k_gemm.hip: p.ksplit).
+// Tile codes 65064 / 65128 of launch_gemm.
+void launch_gemm_ring(const GemmParams & p, int epilogue, int bn, hipStream_t stream);
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);
@@ -125,6 +132,7 @@ struct SkinnyParams {
     float2 * stats_out = nullptr;        // EPI_RESID_F32: [row][stats_cap], entry blockIdx.x = statistics of the row over this workgroup's 16 columns
     int stats_cap = 128;
 };
+constexpr int SKINNY_MAX_ROWS = 512;    // rows the statistics buffers are sized for ([2][SKINNY_MAX_ROWS][stats_cap] float2)
 bool skinny_supported(const SkinnyParams & p, int epilogue);
 void launch_skinny(const SkinnyParams & p, int epilogue, hipStream_t stream);
 void launch_row_stats(const float * x, int ldx, int rows, int h, float2 * stats, hipStream_t stream);   // slot 0 := statistics of every row

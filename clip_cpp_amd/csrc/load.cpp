@@ -506,7 +506,7 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         if (hipMalloc(&w, nfl * sizeof(float)) != hipSuccess || hipMalloc(&c, 4096 * sizeof(unsigned)) != hipSuccess || hipMemset(c, 0, 4096 * sizeof(unsigned)) != hipSuccess)
             return fail("hipMalloc (split-K workspace) failed");
         ctx->sk_ws = (float *)w; ctx->sk_ws_floats = nfl; ctx->sk_cnt = (unsigned *)c; ctx->sk_cnt_n = 4096;
-        if (hipMalloc((void **)&ctx->sk_stats, (size_t)2 * 128 * 128 * sizeof(float2)) != hipSuccess) return fail("hipMalloc (LayerNorm statistics) failed");
+        if (hipMalloc((void **)&ctx->sk_stats, (size_t)2 * SKINNY_MAX_ROWS * 128 * sizeof(float2)) != hipSuccess) return fail("hipMalloc (LayerNorm statistics) failed");
     }
     ctx->weights_bytes = L.st.size + 256;
     if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");

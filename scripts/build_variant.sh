@@ -10,6 +10,10 @@ B=clip_cpp_amd/build; V=clip_cpp_amd/variants/$NAME; mkdir -p $V
 for wt in 0 1 2 3 4 5; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -DCLIPAMD_GEMM_WT=$wt -c clip_cpp_amd/csrc/k_gemm.hip -o $V/k_gemm_wt$wt.o &
 done
+for wt in 0 1 2 3 4 5; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -Iinclude "$@" -DCLIPAMD_RING_WT=$wt -c clip_cpp_amd/csrc/k_gemm_ring.hip -o $V/k_gemm_ring_wt$wt.o &
+done
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm_ring.hip -o $V/k_gemm_ring.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm.hip -o $V/k_gemm.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm8.hip -o $V/k_gemm8.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm4.hip -o $V/k_gemm4.hip.o &

@@ -28,11 +28,16 @@ SHAPES = [  # (name, M, N, K, epi)
     ("sq.k1k", 4096, 4096, 1024, 1), ("sq.k8k", 4096, 4096, 8192, 1), ("sq8.k4k", 8192, 8192, 4096, 1),
     ("b128.qkv", 6400, 2304, 768, 1), ("b128.out", 6400, 768, 768, 4), ("b128.up", 6400, 3072, 768, 3), ("b128.down", 6400, 768, 3072, 4),
 ]
+for a in sys.argv[1:]:      # custom shapes: MxNxK[:epi]  (epi as clip_amd_bench_gemm: 1 f16, 3 quick-gelu f16, 4 residual)
+    if a.count("x") == 2 and a.replace("x", "").replace(":", "").isdigit():
+        dims, _, e = a.partition(":")
+        M_, N_, K_ = (int(v) for v in dims.split("x"))
+        SHAPES.append((a + ".", M_, N_, K_, int(e) if e else 1))
 tiles = [int(t) for t in sys.argv[1:] if t.isdigit()] or [0]
 if 'ksweep' in sys.argv[1:]:
     tiles = [0] + [ks * 1000000 + t for t in (64064, 64128, 128128, 160128) for ks in (1, 2, 3, 4, 6, 8)]
 types = [t for t in sys.argv[1:] if t in TYPES] or ["q4_0"]
-only = [a for a in sys.argv[1:] if "." in a]
+only = [a for a in sys.argv[1:] if "." in a] + [a + "." for a in sys.argv[1:] if a.count("x") == 2]
 debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]
 ITERS = int(os.environ.get("GEMM_ITERS", "20"))   # long runs (thousands) show the sustained, power-limited rate
 PRE = (1 << 16) if "pre" in sys.argv[1:] else 0   # 8-wave kernel: time the GEMM alone on an already dequantised fp16 panel (per-layer form)

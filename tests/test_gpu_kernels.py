@@ -106,7 +106,7 @@ def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
     assert np.array_equal(base, y), _diff_report(base, y)
 
 
-@pytest.mark.parametrize("ksplit,tile", [(2, 64064), (3, 64064), (5, 64128), (12, 64064)])
+@pytest.mark.parametrize("ksplit,tile", [(2, 64064), (3, 64064), (5, 64128), (12, 64064), (3, 65064), (4, 65128)])
 @pytest.mark.parametrize("tname,epi", [("q4_0", 4), ("f16", 1), ("q8_0", 3), ("q5_1", 0)])
 def test_gemm_split_k_is_deterministic_and_matches_unsplit(L, ksplit, tile, tname, epi):
     """Small-M path: K split over `ksplit` workgroups per tile with the in-kernel ordered fix-up.  Two runs give the
@@ -127,6 +127,63 @@ def test_gemm_split_k_is_deterministic_and_matches_unsplit(L, ksplit, tile, tnam
     assert np.abs(a - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
     auto = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=0)     # heuristic (splits here)
     assert np.abs(auto - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
+
+
+RING_TILES = [65064, 65128]     # k_gemm_ring.hip: 64 activation rows x 64 / 128 weight rows, LDS ring of K-tiles
+
+
+@pytest.mark.parametrize("tile", RING_TILES)
+@pytest.mark.parametrize("tname", ["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+@pytest.mark.parametrize("shape,epi", [((203, 320, 192), 0), ((1600, 768, 768), 4), ((130, 2304, 768), 1), ((333, 512, 2048), 3), ((77, 80, 64), 2)])
+def test_gemm_ring_kernel_is_bitwise_identical_to_the_two_buffer_kernel(L, tile, tname, shape, epi):
+    """The mid-M ring kernel (raw-quant staging, dequantisation per MFMA fragment, 3-4 K-tiles in flight, counted waits) accumulates
+    in the same k order from the same fp16 operand values as k_gemm.hip: identical bits for every weight type, M / N edges
+    (rows and weight rows past the end are clamped reads), K-tile counts from 1 (shorter than the ring) to 48, all epilogues."""
+    M, N, K = shape
+    rng = np.random.default_rng(hash((shape, tname)) % (2 ** 31))
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=64064)
+    y = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=tile)
+    assert np.array_equal(base, y), _diff_report(base, y)
+
+
+@pytest.mark.parametrize("tile", RING_TILES)
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 448])
+def test_gemm_ring_lengths_around_the_ring_depth(L, tile, K):
+    """1 … 7 K-tiles: fewer tiles than ring stages (the prologue's clamped requests), exactly the ring depth, one more."""
+    rng = np.random.default_rng(K + tile)
+    M, N = 150, 384
+    for tname in ("q4_0", "q5_1", "f16"):
+        tid = ref.GGML_TYPES[tname]
+        raw = ref.quantize(tid, _weights(rng, N, K))
+        X = rng.standard_normal((M, K)).astype(np.float32)
+        base = run_gemm(L, tid, raw, N, K, X, epi=0, tile=64064)
+        y = run_gemm(L, tid, raw, N, K, X, epi=0, tile=tile)
+        assert np.array_equal(base, y), (tname, _diff_report(base, y))
+
+
+def test_gemm_ring_race_screen(L):
+    """Many tiles, repeated: a missing wait or barrier in the ring (a stage overwritten while it is read, a tile read before it
+    landed) shows up as run-to-run differences under load."""
+    rng = np.random.default_rng(7)
+    M, N, K = 2500, 1536, 1024
+    tid = ref.GGML_TYPES["q4_0"]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    base = run_gemm(L, tid, raw, N, K, X, epi=0, tile=64064)
+    for tile in RING_TILES + [2000000 + 65128, 3000000 + 65064]:
+        first = run_gemm(L, tid, raw, N, K, X, epi=0, tile=tile)
+        if tile < 1000000:
+            assert np.array_equal(base, first), (tile, _diff_report(base, first))
+        else:
+            assert np.abs(first - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
+        for _ in range(5):
+            again = run_gemm(L, tid, raw, N, K, X, epi=0, tile=tile)
+            assert np.array_equal(first, again), (tile, _diff_report(first, again))
 
 
 @pytest.mark.parametrize("epi", [1, 2, 3, 4])
@@ -393,9 +450,11 @@ def run_skinny(L, tid, raw, N, K, X, bias=None, resid=None, ln=None, epi=0, qcol
 
 
 @pytest.mark.parametrize("tname", TYPES[:6])
-@pytest.mark.parametrize("M,N,K", [(50, 768, 768), (1, 512, 512), (49, 1536, 512), (64, 768, 3072), (50, 2304, 768), (64, 1024, 4096), (17, 80, 64)])
+@pytest.mark.parametrize("M,N,K", [(50, 768, 768), (1, 512, 512), (49, 1536, 512), (64, 768, 3072), (50, 2304, 768), (64, 1024, 4096), (17, 80, 64),
+                                   (100, 768, 3072), (257, 512, 512)])
 def test_skinny_gemm_vs_dequant_reference_and_tiled_kernel(L, tname, M, N, K):
-    """k_skinny.hip (M <= 128): every weight type, both wave counts (K >= 2048 -> 8 waves), both row-fragment counts (M <= 64 / <= 128),
+    """k_skinny.hip (one 16-row block per workgroup, rows split over grid.y): every weight type, both wave counts (K >= 2048 -> 8 waves),
+    one to 17 row blocks incl. a ragged last one,
     f32 / residual / f16 epilogues: elementwise bound against the float64 product of the dequantised operands, and within fp32
     re-association of the tiled kernel's result."""
     rng = np.random.default_rng(M * 1000 + N + K)
@@ -418,14 +477,15 @@ def test_skinny_gemm_vs_dequant_reference_and_tiled_kernel(L, tname, M, N, K):
     assert np.all(np.abs(yr - (lin + resid)) <= bound + 1e-6 * np.abs(resid))
     # the partial statistics the residual epilogue leaves: per row, over each workgroup's 16 columns
     if (N + 15) // 16 <= 128:                                  # (the residual GEMMs of a model have N = hidden size <= 2048)
-        s1 = stats[:M, : (N + 15) // 16, 0].sum(1)
-        s2 = stats[:M, : (N + 15) // 16, 1].sum(1)
-        np.testing.assert_allclose(s1, yr.astype(np.float64).sum(1), rtol=1e-4, atol=1e-3)
-        np.testing.assert_allclose(s2, (yr.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+        Ms = min(M, 128)                                       # (the hook returns the statistics of the first 128 rows)
+        s1 = stats[:Ms, : (N + 15) // 16, 0].sum(1)
+        s2 = stats[:Ms, : (N + 15) // 16, 1].sum(1)
+        np.testing.assert_allclose(s1, yr[:Ms].astype(np.float64).sum(1), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(s2, (yr[:Ms].astype(np.float64) ** 2).sum(1), rtol=1e-4)
 
 
 @pytest.mark.parametrize("tname", ["q4_0", "f16", "q5_1"])
-@pytest.mark.parametrize("M,N,K,epi", [(50, 2304, 768, 1), (50, 3072, 768, 3), (64, 2048, 512, 2), (33, 3072, 1024, 3), (1, 1280, 1280, 1)])
+@pytest.mark.parametrize("M,N,K,epi", [(50, 2304, 768, 1), (50, 3072, 768, 3), (64, 2048, 512, 2), (33, 3072, 1024, 3), (1, 1280, 1280, 1), (150, 1536, 512, 1)])
 def test_skinny_layernorm_fused_projection(L, tname, M, N, K, epi):
     """LN fused on the A operand: out = act(LayerNorm(x) . W^T + b) with LayerNorm as in the standalone kernel (output rounded to fp16
     before the product).  Reference: float64 LayerNorm -> fp16 -> float64 product; the one-pass variance and the fp16 rounding of
