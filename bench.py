@@ -87,7 +87,7 @@ def kernel_source_sha16():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "clip_cpp_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith(".hip") or f == "kernels.h":
+        if f.endswith(".hip") or f in ("kernels.h", "gemm_common.h", "attn_body.h"):    # everything that holds device code
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -7,6 +7,7 @@
 // [rows][3h] projection output and writes the merged [rows][h] context).  Q arrives pre-scaled by
 // 1/sqrt(d_head) (GEMM epilogue; the reference scales Q after the bias, clip.cpp:1363).
 //
+// (Device code in attn_body.h: also the second phase of the fused small-M kernel, k_qkv_attn.hip.)
 // One workgroup (4 waves) per (sequence, head).  K ([T][dh]) and V^T ([dh][T]) of the head are staged
 // once in LDS (zero padded to the compile-time tile count); each wave then owns 16-query blocks:
 //   S^T = K · Q^T        v_mfma_f32_16x16x32_f16, A = K rows (keys), B = Q rows (queries)

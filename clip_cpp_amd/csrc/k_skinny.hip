@@ -9,8 +9,11 @@
 // split-K ticket hand-off through L2, and LayerNorm as a separate launch in front of every q/k/v and FFN-up projection.
 // Here the structure is that of a decode GEMV (cdna_hip_programming.md §5 "GEMV / M <= 16": no LDS round trip, deep unroll):
 //
-//   * one workgroup per 16 output columns (N / 16 workgroups: 144 for the ViT-B/32 q/k/v projection); its NW waves split K
-//     into NW contiguous ranges — an intra-workgroup split-K that is reduced through LDS in wave order (deterministic);
+//   * one workgroup per 16 output columns x 16 rows (N / 16 x ceil(M / 16) workgroups: 192-768 for one ViT-B/32 image; grid.x =
+//     column group, a multiple of 8 for every CLIP width, so the row blocks of a column group share one XCD's L2 copy of the
+//     weight slab); its NW waves split K into NW contiguous ranges — an intra-workgroup split-K that is reduced through LDS in
+//     wave order (deterministic).  (First form, r02: all <= 64 rows in one workgroup per column group — 48 workgroups for the
+//     N = 768 GEMMs, 13 us per launch; with the rows over grid.y: one image 0.572 -> 0.430 ms.)
 //   * weights never touch LDS: a lane loads ONE 32-bit word of packed quants (+ the block scale) per 16 x 32 MFMA A-fragment
 //     straight from the block-column-major planes (16 rows x 16 B = 256 contiguous bytes per wave instruction) and
 //     dequantises it in registers (dequant_wfrag: the same packed-fp16 arithmetic as the tiled kernels); fp16 weights are read
@@ -22,8 +25,8 @@
 //     slot blockIdx.x; the consumer adds the slots in order — no atomics, bit-reproducible;
 //   * loads are issued in chunks two deep (next chunk in flight while the current one is multiplied), so a workgroup costs
 //     about one memory round trip + <= 24 MFMAs + the LDS reduction.
-//   A transformer layer at M <= 128 is then 5 launches (LN1+QKV, attention, out-proj+residual, LN2+FFN-up+GELU,
-//   FFN-down+residual) instead of 7, each a few microseconds.
+//   A transformer layer at M <= 64 is then 5 launches (LN1+QKV, attention, out-proj+residual, LN2+FFN-up+GELU, FFN-down+residual)
+//   instead of 7, each a few microseconds — 4 where d_head = 64: k_qkv_attn.hip fuses the first two.
 //
 // Numerics: fp32 accumulation split in NW partial sums per output (fixed order) and LayerNorm variance as E[x^2] - mean^2 —
 // the same class of fp32 re-association as the split-K path this replaces (tests: batch-1 vs batch-N rows agree to 1e-6 in

@@ -113,8 +113,8 @@ void launch_gemm4(const GemmParams & p, int epilogue, hipStream_t stream);
 struct DequantJobs { DevWeight W[4]; half_t * out[4]; int blk_end[4]; int n = 0; };
 void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, hipStream_t stream);
 
-// k_skinny.hip: latency-oriented weight GEMM for M <= 64 rows (one image, one text): N / 16 workgroups, weights dequantised in
-// registers straight from the planes, intra-workgroup split-K, optional LayerNorm fused on the A operand (A = LN(x32) with row
+// k_skinny.hip: latency-oriented weight GEMM for small M (one image, one text; the layers use it up to 64 rows): N / 16 x ceil(M / 16)
+// workgroups, weights dequantised in registers straight from the planes, intra-workgroup split-K, optional LayerNorm fused on the A operand (A = LN(x32) with row
 // statistics taken from the producer's partial slots) and partial statistics of the new residual rows out of EPI_RESID_F32.
 struct SkinnyParams {
     const half_t * A16 = nullptr;   // fp16 activations [M][lda] ...
