@@ -11,9 +11,9 @@ SRC     := clip_cpp_amd/csrc
 OUT     := clip_cpp_amd/build
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result -Iinclude --offload-arch=$(ARCH) -DCLIPAMD_TEST_HOOKS=$(hooks)
 HOST    := gguf quant load forward tokenizer preprocess image_io jpeg_decode host_pipeline api
-KERNELS := k_attn k_misc k_preproc k_gemm k_gemm8 k_gemm4 k_skinny k_gemm_ring k_qkv_attn
+KERNELS := k_attn k_misc k_preproc k_gemm k_gemm8 k_gemm4 k_skinny k_gemm_ring
 WTS     := 0 1 2 3 4 5
-OBJS    := $(HOST:%=$(OUT)/%.cpp.o) $(KERNELS:%=$(OUT)/%.hip.o) $(WTS:%=$(OUT)/k_gemm_wt%.o) $(WTS:%=$(OUT)/k_skinny_wt%.o) $(WTS:%=$(OUT)/k_gemm_ring_wt%.o) $(WTS:%=$(OUT)/k_qkv_attn_wt%.o)
+OBJS    := $(HOST:%=$(OUT)/%.cpp.o) $(KERNELS:%=$(OUT)/%.hip.o) $(WTS:%=$(OUT)/k_gemm_wt%.o) $(WTS:%=$(OUT)/k_skinny_wt%.o) $(WTS:%=$(OUT)/k_gemm_ring_wt%.o)
 
 all: clip_cpp_amd/libclip.so clip_cpp_amd/libggml.so
 
@@ -27,8 +27,6 @@ $(OUT)/k_gemm_wt%.o: $(SRC)/k_gemm.hip $(wildcard $(SRC)/*.h) | $(OUT)
 	$(HIPCC) $(CXXFLAGS) -DCLIPAMD_GEMM_WT=$* -c $< -o $@
 $(OUT)/k_skinny_wt%.o: $(SRC)/k_skinny.hip $(wildcard $(SRC)/*.h) | $(OUT)
 	$(HIPCC) $(CXXFLAGS) -DCLIPAMD_SKINNY_WT=$* -c $< -o $@
-$(OUT)/k_qkv_attn_wt%.o: $(SRC)/k_qkv_attn.hip $(wildcard $(SRC)/*.h) | $(OUT)
-	$(HIPCC) $(CXXFLAGS) -DCLIPAMD_QA_WT=$* -c $< -o $@
 $(OUT)/k_gemm_ring_wt%.o: $(SRC)/k_gemm_ring.hip $(wildcard $(SRC)/*.h) | $(OUT)
 	$(HIPCC) $(CXXFLAGS) -DCLIPAMD_RING_WT=$* -c $< -o $@
 clip_cpp_amd/libclip.so: $(OBJS)

@@ -23,7 +23,7 @@ ARCH = "gfx950"
 
 HOST_SOURCES = ["gguf.cpp", "quant.cpp", "load.cpp", "forward.cpp", "tokenizer.cpp", "preprocess.cpp", "image_io.cpp",
                 "jpeg_decode.cpp", "host_pipeline.cpp", "api.cpp"]
-HIP_SOURCES = ["k_attn.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip", "k_gemm4.hip", "k_skinny.hip", "k_gemm_ring.hip", "k_qkv_attn.hip"]
+HIP_SOURCES = ["k_attn.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip", "k_gemm4.hip", "k_skinny.hip", "k_gemm_ring.hip"]
 GEMM_WTYPES = [0, 1, 2, 3, 4, 5]
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
@@ -83,12 +83,6 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or _newer(o, [s] + headers):
             jobs.append([cc, "--offload-arch=" + ARCH] + COMMON + ["-DCLIPAMD_SKINNY_WT=%d" % wt, "-c", s, "-o", o])
-    s = os.path.join(CSRC, "k_qkv_attn.hip")     # the fused LN1 + q/k/v + attention kernel of the small-M path
-    for wt in GEMM_WTYPES:
-        o = os.path.join(BUILD, "k_qkv_attn_wt%d.o" % wt)
-        objs.append(o)
-        if force or _newer(o, [s] + headers):
-            jobs.append([cc, "--offload-arch=" + ARCH] + COMMON + ["-DCLIPAMD_QA_WT=%d" % wt, "-c", s, "-o", o])
     s = os.path.join(CSRC, "k_gemm_ring.hip")    # and the mid-M ring kernel
     for wt in GEMM_WTYPES:
         o = os.path.join(BUILD, "k_gemm_ring_wt%d.o" % wt)

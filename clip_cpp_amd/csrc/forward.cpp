@@ -156,11 +156,6 @@ int skinny_row_limit() {     // rows up to which the small-M kernels carry the l
     return lim;
 }
 
-bool fused_qkv_attn_enabled() {     // CLIP_AMD_FUSED_QKV=0: keep LN1 + q/k/v and the attention as two launches (A/B, tests); read per call
-    const char * e = getenv("CLIP_AMD_FUSED_QKV");
-    return !(e && e[0] == '0');
-}
-
 bool layers_fit_skinny(const DevTower & tw, int rows, int h, int ff) {
     if (!skinny_enabled() || rows <= 0 || rows > skinny_row_limit() || h > 2048 || h % 16 || h / 16 > 128 || tw.layers.empty()) return false;
     const DevLayer & l = tw.layers[0];
@@ -177,17 +172,7 @@ bool run_layers_skinny(clip_ctx * ctx, const DevTower & tw, int rows, int h, int
     float2 * stA = ctx->sk_stats, * stB = ctx->sk_stats + (size_t)SKINNY_MAX_ROWS * 128;
     int slotsA = 1;
     for (const DevLayer & l : tw.layers) {
-        // LN1 + q/k/v projection (+ Q scale after the bias, clip.cpp:1363) + attention: one launch where d_head = 64 (k_qkv_attn.hip)
-        QkvAttnParams f;
-        f.x32 = x; f.ldx = h; f.ln_w = l.ln1_w; f.ln_b = l.ln1_b; f.eps = eps; f.stats_in = stA; f.stats_slots = slotsA;
-        f.W = l.qkv; f.bias = l.qkv_b; f.qscale = qscale; f.qkv = qkv; f.out = att;
-        f.seq_start = d_seq_start; f.T_uniform = T_uniform; f.nseq = nseq; f.max_len = max_len; f.h = h; f.n_head = nh; f.causal = causal ? 1 : 0;
-        if (fused_qkv_attn_enabled() && qkv_attn_supported(f)) {
-            const double fl = 2.0 * rows * (double)l.qkv.N * l.qkv.K + 4.0 * (double)nseq * nh * (double)max_len * max_len * dh;
-            ProfScope ps(ctx, "qkv_attn_kernel/ln1_qkv_attention", rows, l.qkv.N, l.qkv.K, fl, weight_bytes(l.qkv) + (double)rows * h * 4 * nh + (double)rows * h * 2);
-            launch_qkv_attn(f, s);
-        } else {
-        SkinnyParams q;   // LN1 + q/k/v projection
+        SkinnyParams q;   // LN1 + q/k/v projection (+ Q scale after the bias, clip.cpp:1363)
         q.x32 = x; q.ldx = h; q.ln_w = l.ln1_w; q.ln_b = l.ln1_b; q.eps = eps; q.stats_in = stA; q.stats_slots = slotsA;
         q.M = rows; q.W = l.qkv; q.bias = l.qkv_b; q.out = qkv; q.ldc = 3 * h; q.qscale = qscale; q.qcols = h;
         skinny(ctx, "ln1_qkv", q, EPI_F16);
@@ -198,7 +183,6 @@ bool run_layers_skinny(clip_ctx * ctx, const DevTower & tw, int rows, int h, int
                 fprintf(stderr, "clip (hip): attention kernel does not support T=%d d_head=%d\n", max_len, dh);
                 return false;
             }
-        }
         }
         SkinnyParams o;   // out-projection + residual; leaves the statistics of the new rows for LN2
         o.A16 = att; o.lda = h; o.M = rows; o.W = l.o; o.bias = l.o_b; o.out = x; o.ldc = h; o.resid = x; o.stats_out = stB;

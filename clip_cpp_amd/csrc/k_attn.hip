@@ -7,7 +7,6 @@
 // [rows][3h] projection output and writes the merged [rows][h] context).  Q arrives pre-scaled by
 // 1/sqrt(d_head) (GEMM epilogue; the reference scales Q after the bias, clip.cpp:1363).
 //
-// (Device code in attn_body.h: also the second phase of the fused small-M kernel, k_qkv_attn.hip.)
 // One workgroup (4 waves) per (sequence, head).  K ([T][dh]) and V^T ([dh][T]) of the head are staged
 // once in LDS (zero padded to the compile-time tile count); each wave then owns 16-query blocks:
 //   S^T = K · Q^T        v_mfma_f32_16x16x32_f16, A = K rows (keys), B = Q rows (queries)
@@ -23,20 +22,270 @@
 // T <= 288 for every d_head in {32,64,80,96} (all 224-px models and every text length); T <= 592 for d_head <= 64
 // (ViT-L/14 at 336 px: T = 577, 154.6 KB of LDS); longer sequences are rejected by the launcher.
 
-#include "attn_body.h"
+#include "kernels.h"
 
 namespace clipamd {
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
+
+struct AttnParams {
+    const half_t * qkv;   // [rows][3h]
+    half_t * out;         // [rows][h]
+    const int * seq_start;
+    int T_uniform;
+    int h, n_head;
+    int causal;
+};
+
+// Everything a wave needs to process query blocks of one (sequence, head): LDS tiles, global Q / output rows.
+template <int NT, int DKS, int DT>
+struct AttnTile {
+    const half_t * Ks;
+    const half_t * Vt;
+    const half_t * Qg;
+    half_t * Og;          // output rows of this sequence, already offset to the head's columns
+    int ld, h, len, causal, fq, fg;
+};
+
+// QB consecutive 16-query blocks starting at block qb0 (blocks beyond the sequence are computed on clamped rows and not stored).
+template <int NT, int DKS, int DT, int QB>
+__device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int qb0) {
+    constexpr int DKP = DKS * 32;
+    constexpr bool SWZ = NT > 18;
+    constexpr int KSTRIDE = SWZ ? DKP : DKP + 8;
+    constexpr int NPR = (NT + 1) / 2;
+    constexpr int VSTRIDE = NPR * 32 + 8;
+    constexpr int DH = DT * 16;
+    const int fq = t.fq, fg = t.fg, len = t.len;
+    // Q fragments (MFMA B operand): query row qb*16+fq, d = kk*32 + fg*8 .. +7
+    h8 qf[QB][DKS];
+    int qrow[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        qrow[j] = (qb0 + j) * 16 + fq;
+        const int qclamped = qrow[j] < len ? qrow[j] : len - 1;
+#pragma unroll
+        for (int kk = 0; kk < DKS; kk++) {
+            const int d0 = kk * 32 + fg * 8;
+            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+            if (d0 < DH) v = *(const u32x4 *)(t.Qg + (size_t)qclamped * t.ld + d0);
+            qf[j][kk] = __builtin_bit_cast(h8, v);
+        }
+    }
+    // ---- S^T tiles (unconditional MFMA chain); one K fragment read feeds QB MFMAs ----
+    f4 s[QB][NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+#pragma unroll
+        for (int j = 0; j < QB; j++) s[j][kt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DKS; kk++) {
+            const int kch = kk * 4 + fg;
+            const h8 kf = *(const h8 *)(t.Ks + (kt * 16 + fq) * KSTRIDE + (SWZ ? (kch ^ (fq & 7)) : kch) * 8);
+#pragma unroll
+            for (int j = 0; j < QB; j++) s[j][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[j][kk], s[j][kt], 0, 0, 0);
+        }
+        // keep at most 4 key tiles (8 fragment reads) in flight: fully hoisted, the reads of all NT tiles cost
+        // 4*2*NT VGPRs (NT = 18: 488 registers, one workgroup per CU)
+        if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- mask + softmax.  lane holds query fq, keys kt*16 + fg*4 + r ----
+    float inv[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        const int kmax = t.causal ? (qrow[j] < len - 1 ? qrow[j] : len - 1) : len - 1;   // last visible key
+        const int kfull = t.causal ? 0 : (len >> 4);     // key tiles below kfull are entirely visible (uniform): no masking work
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+            if (kt >= kfull) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = kt * 16 + fg * 4 + r;
+                    s[j][kt][r] = key <= kmax ? s[j][kt][r] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[j][kt][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // exp(s - mx) = exp2(s*log2(e) - mx*log2(e)): one fma + the hardware exp2 per score
+        const float L2E = 1.44269504088896340736f;
+        const float nmx = -mx * L2E;                     // key 0 is always visible -> mx is finite
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][r], L2E, nmx));
+                s[j][kt][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[j] = 1.0f / sum;
+    }
+    // ---- O = P V : pairs of key tiles form one K=32 slice; one V^T fragment read feeds QB MFMAs ----
+    f4 o[QB][DT];
+#pragma unroll
+    for (int j = 0; j < QB; j++)
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) o[j][dt] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < NPR; pr++) {
+        h8 pf[QB];
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            const f4 p0 = s[j][2 * pr];
+            f4 p1 = (f4){0.f, 0.f, 0.f, 0.f};
+            if (2 * pr + 1 < NT) p1 = s[j][(2 * pr + 1 < NT) ? 2 * pr + 1 : 0];
+            pf[j][0] = (_Float16)p0[0]; pf[j][1] = (_Float16)p0[1]; pf[j][2] = (_Float16)p0[2]; pf[j][3] = (_Float16)p0[3];
+            pf[j][4] = (_Float16)p1[0]; pf[j][5] = (_Float16)p1[1]; pf[j][6] = (_Float16)p1[2]; pf[j][7] = (_Float16)p1[3];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            const half_t * vrow = t.Vt + (dt * 16 + fq) * VSTRIDE + pr * 32 + fg * 4;
+            const h4 v0 = *(const h4 *)(vrow);
+            const h4 v1 = *(const h4 *)(vrow + 16);
+            h8 vf;
+            vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+            vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+#pragma unroll
+            for (int j = 0; j < QB; j++) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], vf, o[j][dt], 0, 0, 0);
+        }
+        if ((pr & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- normalise rows and store.  O layout: row (query) = fg*4 + r, col (d) = fq ----
+#pragma unroll
+    for (int j = 0; j < QB; j++) {
+        float invr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) invr[r] = __shfl(inv[j], fg * 4 + r);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = (qb0 + j) * 16 + fg * 4 + r;
+            if (q < len) {
+                half_t * orow = t.Og + (size_t)q * t.h + fq;
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++) orow[dt * 16] = (_Float16)(o[j][dt][r] * invr[r]);
+            }
+        }
+    }
+}
 
 // NT  = number of 16-key tiles (>= ceil(max_len/16)); DKS = 32-wide k-steps over the head dim (dh <= 32*DKS);
 // DT = dh/16 output tiles.
+template <int NT, int DKS, int DT>
 // occupancy: short sequences (T <= 80: ViT-B/32 images, every text) are latency-bound — stage, one barrier, a handful of MFMAs — so 4
 // workgroups per CU (<= 128 VGPRs) instead of 2 hide twice the memory latency; long ones need the registers
-template <int NT, int DKS, int DT>
 __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_kernel(const AttnParams p) {
+    constexpr int DKP = DKS * 32;
+    // Long sequences (NT > 18: 336-px models, T = 577) only fit the 160 KB LDS without the row padding: K rows are then
+    // exactly 128 B with the 16-byte chunks XOR-swizzled by (key & 7) instead (same conflict-free ds_read_b128 pattern
+    // as the GEMM tiles); needs DKP == 64.
+    constexpr bool SWZ = NT > 18;
+    static_assert(!SWZ || DKP == 64, "swizzled K layout is for d_head <= 64");
+    constexpr int KSTRIDE = SWZ ? DKP : DKP + 8;     // halfs per K row  (+16 B pad: spreads ds_read_b128 over banks)
+    constexpr int NPR = (NT + 1) / 2;                // key-tile pairs = K=32 slices of the P.V contraction
+    constexpr int VSTRIDE = NPR * 32 + 8;            // halfs per V^T row; (VSTRIDE/2) = 4*odd -> conflict-free ds_read_b64
+    constexpr int DH = DT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    attn_body<NT, DKS, DT, 256>(p, blockIdx.x / p.n_head, blockIdx.x % p.n_head, blockIdx.y, gridDim.y, smem_raw);
+    half_t * Ks = (half_t *)smem_raw;                // [NT*16][KSTRIDE]
+    half_t * Vt = Ks + NT * 16 * KSTRIDE;            // [DH][VSTRIDE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = blockIdx.x / p.n_head, head = blockIdx.x % p.n_head;
+    int row0, len;
+    if (p.seq_start) {
+        row0 = p.seq_start[seq];
+        len = p.seq_start[seq + 1] - row0;
+    } else {
+        row0 = seq * p.T_uniform;
+        len = p.T_uniform;
+    }
+    const int ld = 3 * p.h;
+    const half_t * Qg = p.qkv + (size_t)row0 * ld + head * DH;
+    const half_t * Kg = Qg + p.h;
+    const half_t * Vg = Qg + 2 * p.h;
+    constexpr int DCH = DH / 8;                      // 16-byte chunks per head row
+
+    // ---- stage K: Ks[key][0..DKP) (zero for key >= len and for columns >= DH) and V transposed: Vt[d][key], two keys per
+    // thread so every LDS store is a full dword.  ALL global loads of the workgroup are issued before the first LDS store
+    // (fully unrolled, unconditional clamped addresses + select): left as loops, each thread waited out one memory round
+    // trip per 16-byte chunk (9 + 2x5 serial trips at T = 257 — two thirds of the kernel's time).
+    {
+        constexpr int KCH = DKP / 8;
+        constexpr int KIT = (NT * 16 * KCH + 255) / 256;
+        constexpr int NPAIR = NPR * 16;              // key pairs (covers NPR*32 keys, zero padded)
+        constexpr int VIT = (NPAIR * DCH + 255) / 256;
+        u32x4 kv[KIT], va[VIT], vb[VIT];
+#pragma unroll
+        for (int i = 0; i < KIT; i++) {
+            const int it = tid + i * 256;
+            const int key = it / KCH, c = it % KCH;
+            const int kc = key < len ? key : len - 1, cc = c < DCH ? c : DCH - 1;
+            kv[i] = *(const u32x4 *)(Kg + (size_t)kc * ld + cc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; i++) {
+            const int it = tid + i * 256;
+            const int kp = it % NPAIR, c = (it / NPAIR) < DCH ? (it / NPAIR) : DCH - 1;
+            const int k0 = 2 * kp;
+            va[i] = *(const u32x4 *)(Vg + (size_t)(k0 < len ? k0 : len - 1) * ld + c * 8);
+            vb[i] = *(const u32x4 *)(Vg + (size_t)(k0 + 1 < len ? k0 + 1 : len - 1) * ld + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; i++) {
+            const int it = tid + i * 256;
+            const int key = it / KCH, c = it % KCH;
+            if (it < NT * 16 * KCH) {
+                const u32x4 v = (key < len && c < DCH) ? kv[i] : (u32x4){0u, 0u, 0u, 0u};
+                *(u32x4 *)(Ks + key * KSTRIDE + (SWZ ? (c ^ (key & 7)) : c) * 8) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; i++) {
+            const int it = tid + i * 256;
+            const int kp = it % NPAIR, c = it / NPAIR;
+            const int k0 = 2 * kp;
+            if (it < NPAIR * DCH) {
+                const u32x4 a = k0 < len ? va[i] : (u32x4){0u, 0u, 0u, 0u};
+                const u32x4 b = k0 + 1 < len ? vb[i] : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t av = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    const uint32_t bv = (b[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    *(uint32_t *)(Vt + (c * 8 + e) * VSTRIDE + k0) = av | (bv << 16);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int fq = lane & 15, fg = lane >> 4;
+    const int nqb = (len + 15) >> 4;
+
+    // Query blocks are processed in PAIRS where the register budget allows (QB = 2: every K / V^T fragment read from LDS
+    // feeds two MFMAs, halving the LDS traffic that bounds this kernel at T = 257), the odd last block alone.
+    constexpr int QB = (NT >= 7 && NT <= 18) ? 2 : 1;
+    const AttnTile<NT, DKS, DT> t{Ks, Vt, Qg, p.out + (size_t)row0 * p.h + head * DH, ld, p.h, len, p.causal, fq, fg};
+    // gridDim.y workgroups share one (sequence, head): each stages K / V^T itself and takes every gridDim.y-th set of four work units
+    // (few sequences x heads and many query blocks — one ViT-L/14 image is 16 workgroups of 17 query blocks otherwise)
+    const int slot = wave + 4 * blockIdx.y, nslot = 4 * gridDim.y;
+    if constexpr (QB == 2) {
+        const int npair = nqb >> 1;
+        for (int u = slot; u < npair; u += nslot) attn_blocks<NT, DKS, DT, 2>(t, 2 * u);
+        if ((nqb & 1) && slot == npair % nslot) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
+    } else {
+        for (int qb = slot; qb < nqb; qb += nslot) attn_blocks<NT, DKS, DT, 1>(t, qb);
+    }
 }
 
 template <int NT, int DKS, int DT>

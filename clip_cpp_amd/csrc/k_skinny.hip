@@ -26,7 +26,8 @@
 //   * loads are issued in chunks two deep (next chunk in flight while the current one is multiplied), so a workgroup costs
 //     about one memory round trip + <= 24 MFMAs + the LDS reduction.
 //   A transformer layer at M <= 64 is then 5 launches (LN1+QKV, attention, out-proj+residual, LN2+FFN-up+GELU, FFN-down+residual)
-//   instead of 7, each a few microseconds — 4 where d_head = 64: k_qkv_attn.hip fuses the first two.
+//   instead of 7, each a few microseconds.  (Fusing the first two — LN1 + q/k/v + attention of a (sequence, head) in one workgroup — was
+//   built and measured SLOWER: 23 us against 10.5 + 6.6 for one image; profiles/r02_second_session_experiments.txt section 6.)
 //
 // Numerics: fp32 accumulation split in NW partial sums per output (fixed order) and LayerNorm variance as E[x^2] - mean^2 —
 // the same class of fp32 re-association as the split-K path this replaces (tests: batch-1 vs batch-N rows agree to 1e-6 in

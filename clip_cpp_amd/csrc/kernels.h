@@ -143,28 +143,6 @@ bool skinny_supported(const SkinnyParams & p, int epilogue);
 void launch_skinny(const SkinnyParams & p, int epilogue, hipStream_t stream);
 void launch_row_stats(const float * x, int ldx, int rows, int h, float2 * stats, hipStream_t stream);   // slot 0 := statistics of every row
 
-// k_qkv_attn.hip: small-M path, LayerNorm1 + q/k/v projection + attention of one (sequence, head) per workgroup (d_head = 64,
-// sequences of <= 64 rows): replaces launch_skinny(LN1 + q/k/v) + launch_attention.  qkv: [rows][3h] fp16 scratch (written and read
-// back by the same workgroup), out: [rows][h] fp16.
-struct QkvAttnParams {
-    const float * x32 = nullptr;         // residual stream [rows][ldx]
-    int ldx = 0;
-    const float * ln_w = nullptr, * ln_b = nullptr;
-    float eps = 0.f;
-    const float2 * stats_in = nullptr;   // [row][stats_cap] partial (sum, sum of squares) slots, as SkinnyParams
-    int stats_slots = 0, stats_cap = 128;
-    DevWeight W;                         // fused q/k/v weight [3h][h]
-    const float * bias = nullptr;
-    float qscale = 1.0f;
-    half_t * qkv = nullptr;
-    half_t * out = nullptr;
-    const int * seq_start = nullptr;     // device [nseq + 1], or null: uniform length T_uniform
-    int T_uniform = 0, nseq = 0, max_len = 0;
-    int h = 0, n_head = 0, causal = 0;
-};
-bool qkv_attn_supported(const QkvAttnParams & p);
-void launch_qkv_attn(const QkvAttnParams & p, hipStream_t stream);
-
 // LayerNorm over rows of h floats (ggml_norm + mul + add, reference clip.cpp:1350-1355).
 // Row r reads x[in_rows[r]] when in_rows != nullptr, else x[r * in_row_mul] (strided gather, e.g. the
 // CLS rows b*T); out16/out32 may be null.
