@@ -65,7 +65,7 @@ AMD_SYMBOLS = [
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
-    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_skinny", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
+    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_gemm_tile", "clip_amd_test_skinny", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
 
 _lib = None
@@ -159,6 +159,8 @@ def lib():
     L.clip_amd_test_gemm.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32]
     L.clip_amd_test_gemm_ex.restype = i32
     L.clip_amd_test_gemm_ex.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32, i32, C.c_float, i32, i32, f32p]
+    L.clip_amd_test_gemm_tile.restype = i32
+    L.clip_amd_test_gemm_tile.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32]
     L.clip_amd_test_skinny.restype = i32
     L.clip_amd_test_skinny.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_float, f32p, i32, i32, C.c_float, f32p]
     L.clip_amd_bench_gemm.restype = C.c_float

@@ -549,6 +549,11 @@ int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches,
 #define CLIPAMD_TEST_HOOKS 1
 #endif
 #if CLIPAMD_TEST_HOOKS
+int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised) {
+    const int Kpad = (int)((K + 63) / 64 * 64);
+    return gemm_tile_for((int)M, (int)N, Kpad, quantised != 0);
+}
+
 // Extended form: qcols / qscale (EPI_F16 Q-scale path, clip.cpp:1363) and epilogue 5 = EPI_PATCH_F32 (patch embedding:
 // row m of the GEMM lands in output row (m / Np) * T + 1 + m % Np and gets pos[1 + m % Np] added; no bias; the class-token
 // rows (b * T) are left untouched).  For epilogue 5, y is [(M / Np) * T][N] and pos is [T][N].

@@ -124,10 +124,13 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
 int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M,
                           const float * bias, const float * resid, float * y, int epilogue, int tile,
                           int qcols, float qscale, int Np, int T, const float * pos);
+/* The tile the heuristic of launch_gemm picks for an [M][K] x [N][K]^T problem (pure host arithmetic, no device needed):
+ * BM * 1000 + BN; BM = 65: the mid-M ring kernel on 64-row tiles (k_gemm_ring.hip), BN = 256 / 258-260: the large-M panel kernels. */
+int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised);
 /* Average device time (microseconds, HIP events) of one GEMM shape through the production kernel on random
  * weights of ggml type `type`; < 0 on error.  Used by scripts/gemm_bench.py for kernel A/B work. */
 float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters);
-/* Small-M kernel (M <= 64 rows: one image / one text; k_skinny.hip): y[M][N] = epilogue(A . W^T + bias) with A = fp16(x), or — ln_w
+/* Small-M kernel (one image / one text: the layers use it up to 64 rows, the hook up to 512; k_skinny.hip): y[M][N] = epilogue(A . W^T + bias) with A = fp16(x), or — ln_w
  * != NULL — A = LayerNorm(x) fused into the kernel.  epilogue 0 f32, 1 f16 (+ qcols / qscale), 2 gelu, 3 quick-gelu, 4 residual
  * (stats_out, if not NULL, receives the [128 rows][128 slots][2] partial row statistics the epilogue leaves for the next LayerNorm:
  * slot j of a row = its (sum, sum of squares) over output columns 16 j .. 16 j + 15).

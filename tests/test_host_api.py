@@ -346,3 +346,32 @@ def test_malformed_and_unsupported_files_are_rejected_at_load(clip_lib, tmp_path
         assert not L.clip_model_load(os.fsencode(path), 0), needle
         err = capfd.readouterr().err
         assert needle in err, (needle, err)
+
+
+def test_gemm_tile_heuristic_covers_the_model_shapes(clip_lib):
+    """launch_gemm's tile choice is host arithmetic (clip_amd_test_gemm_tile): every shape of the target matrix maps to a tile code that exists,
+    the regimes land where the measured sweeps put them (profiles/r02_ring_sweep_*.txt, r02_gemm8_experiments.txt), and the choice is monotone
+    in the obvious sense (no ring tiles for one image's rows or for batch 256)."""
+    L = clip_lib.lib()
+    tile = lambda M, N, K, q=1: L.clip_amd_test_gemm_tile(M, N, K, q)
+    known = {64064, 64128, 128064, 128128, 160128, 192128, 65064, 65128, 160256, 256260}
+    models = {"b32": (50, 768, 3072), "b32t": (40, 512, 2048), "l14": (257, 1024, 4096), "l14t": (40, 768, 3072), "h14": (257, 1280, 5120)}
+    for name, (T, h, ff) in models.items():
+        for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 1024):
+            for N, K in ((3 * h, h), (h, h), (ff, h), (h, ff)):
+                for q in (0, 1):
+                    t = tile(B * T, N, K, q)
+                    assert t in known, (name, B, N, K, q, t)
+    # <= 64 rows: the two-buffer 64 x 64 tile (the layers themselves run on k_skinny.hip there)
+    assert tile(50, 768, 768) == 64064 and tile(13, 512, 2048) == 64064
+    # mid-M: the ring kernel where the sweep has it ahead ...
+    assert tile(1600, 2304, 768) == 65128 and tile(1600, 768, 768) == 65128 and tile(1600, 768, 3072) == 65128      # ViT-B/32 batch 32: q/k/v, out, FFN down
+    assert tile(1600, 3072, 768) == 160128                                                                           # ... its FFN up stays on the big tile
+    assert tile(257, 3072, 1024, 0) == 65064 and tile(257, 4096, 1024, 0) == 65128 and tile(257, 1024, 4096, 0) == 65064   # one ViT-L/14 image, f16
+    assert tile(1280, 512, 512) == 65064 and tile(1280, 1536, 512) == 65128                                          # a batch of 32 texts
+    assert tile(514, 768, 3072, 1) == 64064 or tile(514, 768, 3072, 1) // 1000 == 64                                 # quantised long K below ~1000 rows: split-K form
+    assert tile(1568, 768, 3072, 0) == 65064                                                                         # patch embedding of 32 images (f16 kernel)
+    # batch 256 and beyond: never the ring
+    for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+        assert tile(12800, N, K) // 1000 in (128, 160, 192), (N, K, tile(12800, N, K))
+    assert tile(65792, 4096, 1024, 0) == 256260 and tile(65792, 1024, 4096, 0) == 256260                             # ViT-L/14 batch 256: four-wave 256 x 256
