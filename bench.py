@@ -266,7 +266,7 @@ def main():
         # aggregate by kernel instantiation (= rocprofv3 kernel name), the roofline is quoted for the one with most time
         inst = {}
         for k, v in rep.items():
-            if not k.startswith("gemm"):
+            if not (k.startswith("gemm") or k.startswith("skinny_kernel")):     # the weight-GEMM kernels (tiled, ring, small-M)
                 continue
             name = k.split("/")[0]
             a = inst.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, shapes=set()))
@@ -303,7 +303,7 @@ def main():
             hbm_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
             main, other = (hbm_view, mfma_view) if t_hbm > t_mfma else (mfma_view, hbm_view)
             roofline = dict(main)
-            roofline.update({"kernel": dom + " (fp16 MFMA GEMM; template args as in the rocprofv3 kernel name)",
+            roofline.update({"kernel": dom + " (fp16 MFMA weight GEMM; template args as in the rocprofv3 kernel name)",
                              "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
                              "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l,
                              "t_mfma_us": round(t_mfma * 1e6, 2), "t_hbm_us": round(t_hbm * 1e6, 2), "other_bound": other,

@@ -139,7 +139,9 @@ bool skinny_enabled() {
 void skinny(clip_ctx * ctx, const char * what, const SkinnyParams & p, int epi) {
     if (!ctx->profiling) { launch_skinny(p, epi, ctx->stream); return; }
     char fam[96];
-    snprintf(fam, sizeof fam, "skinny_kernel<%d,%d,%s>/%s", p.W.wtype, epi, p.x32 ? "ln" : "f16", what);
+    // tag = kernel instantiation as rocprofv3 prints it: skinny_kernel<WT, MF, NW, EPI, LNA> (MF = 1; 8 waves for the long-K residual / patch GEMMs)
+    const int nw = (!p.x32 && p.W.Kpad >= 2048 && (epi == EPI_RESID_F32 || epi == EPI_PATCH_F32)) ? 8 : 4;
+    snprintf(fam, sizeof fam, "skinny_kernel<%d,1,%d,%d,%s>/%s", p.W.wtype, nw, epi, p.x32 ? "true" : "false", what);
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double by = weight_bytes(p.W) + (double)p.M * p.W.K * (p.x32 ? 4 : 2) + (double)p.M * p.W.N * (epi == EPI_RESID_F32 ? 8 : epi == EPI_F32 || epi == EPI_PATCH_F32 ? 4 : 2);
     ProfScope ps(ctx, fam, p.M, p.W.N, p.W.K, fl, by);
