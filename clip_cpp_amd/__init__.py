@@ -159,6 +159,9 @@ def lib():
     L.clip_amd_test_gemm.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32]
     L.clip_amd_test_gemm_ex.restype = i32
     L.clip_amd_test_gemm_ex.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, i32, i32, i32, C.c_float, i32, i32, f32p]
+    L.clip_amd_test_lnfold.restype = i32
+    L.clip_amd_test_lnfold.argtypes = [i32, vp, C.c_int64, C.c_int64, vp, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_float, f32p,
+                                       i32, i32, i32, i32, i32, C.c_float, f32p, f32p]
     L.clip_amd_test_gemm_tile.restype = i32
     L.clip_amd_test_gemm_tile.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32]
     L.clip_amd_test_skinny.restype = i32

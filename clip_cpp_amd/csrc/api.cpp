@@ -613,6 +613,73 @@ int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, co
     return rc;
 }
 
+// LayerNorm fold A/B (gemm_common.h): residual GEMM -> LayerNorm -> consumer GEMM, as three launches (fold = 0) or as two with the
+// LayerNorm folded into the epilogues (fold = 1).  See include/clip_amd.h.
+int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, const void * w2_raw, int64_t N2, const float * a, int64_t M,
+                         const float * b1, const float * resid, const float * gamma, const float * beta, float eps, const float * b2,
+                         int epi2, int tile1, int tile2, int fold, int qcols, float qscale, float * x1_out, float * y_out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); fprintf(stderr, "clip_amd_test_lnfold: no HIP device\n"); return -1; }
+    if (h % 64 || epi2 < 1 || epi2 > 3) return -3;
+    DevWeight W1, W2;
+    void * w1base = nullptr, * w2base = nullptr;
+    if (!repack_for_test(type, w1_raw, h, K1, W1, &w1base)) return -2;
+    if (!repack_for_test(type, w2_raw, N2, h, W2, &w2base)) { (void)hipFree(w1base); return -2; }
+    const int st_stride = (int)((M + 63) & ~(int64_t)63);
+    DBuf da32((size_t)M * K1 * 4), da16((size_t)(M + 1) * W1.Kpad * 2), dx((size_t)M * h * 4), dxn((size_t)(M + 1) * W2.Kpad * 2), dy16((size_t)M * N2 * 2),
+        dy32((size_t)M * N2 * 4), db1((size_t)h * 4), db2((size_t)N2 * 4), dg((size_t)h * 4), dbeta((size_t)h * 4), dc((size_t)N2 * 4), dbf((size_t)N2 * 4),
+        dstats((size_t)(h / 32) * st_stride * 8);
+    hipStream_t s = nullptr;
+    (void)hipMemcpy(da32.p, a, (size_t)M * K1 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dx.p, resid, (size_t)M * h * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db1.p, b1, (size_t)h * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db2.p, b2, (size_t)N2 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dg.p, gamma, (size_t)h * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dbeta.p, beta, (size_t)h * 4, hipMemcpyHostToDevice);
+    (void)hipMemset(dxn.p, 0, (size_t)(M + 1) * W2.Kpad * 2);
+    launch_f32_to_f16((const float *)da32.p, (int)K1, (half_t *)da16.p, W1.Kpad, (int)M, (int)K1, W1.Kpad, s);
+    DBuf skw((size_t)64 << 20), skc(4096 * 4);
+    (void)hipMemset(skc.p, 0, 4096 * 4);
+    DBuf panel1((size_t)W1.Npad * W1.Kpad * 2), panel2((size_t)W2.Npad * W2.Kpad * 2);
+    auto common = [&](GemmParams & p, const DBuf & panel, const DevWeight & W) {
+        p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)16 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
+        p.w16_scratch = (half_t *)panel.p; p.w16_scratch_halfs = panel.p ? (size_t)W.Npad * W.Kpad : 0;
+    };
+    GemmParams p1;
+    p1.A = (const half_t *)da16.p; p1.lda = W1.Kpad; p1.M = (int)M; p1.W = W1; p1.bias = (const float *)db1.p; p1.out = dx.p; p1.ldc = (int)h;
+    p1.resid = (const float *)dx.p;
+    common(p1, panel1, W1);
+    GemmParams p2;
+    p2.A = (const half_t *)dxn.p; p2.lda = W2.Kpad; p2.M = (int)M; p2.W = W2; p2.out = dy16.p; p2.ldc = (int)N2; p2.qcols = qcols; p2.qscale = qscale;
+    common(p2, panel2, W2);
+    const int epi = epi2 == 1 ? EPI_F16 : epi2 == 2 ? EPI_GELU_F16 : EPI_QGELU_F16;
+    if (fold) {
+        launch_fold_vectors(W2, (const float *)dg.p, (const float *)dbeta.p, (const float *)db2.p, (float *)dc.p, (float *)dbf.p, s);
+        p1.xg_out = (half_t *)dxn.p; p1.ldxg = W2.Kpad; p1.xg_gamma = (const float *)dg.p; p1.stats_out = (float2 *)dstats.p; p1.stats_stride = st_stride;
+        int t1 = tile1 ? tile1 : gemm_tile_for((int)M, (int)h, W1.Kpad, W1.wtype != W_F16);
+        const int slotw = gemm_fold_slotw(t1);
+        launch_gemm(p1, EPI_RESID_F32, tile1, s);
+        p2.bias = (const float *)dbf.p; p2.ln_c = (const float *)dc.p; p2.ln_stats = (const float2 *)dstats.p; p2.ln_slotw = slotw; p2.ln_slots = (int)h / slotw;
+        p2.ln_stride = st_stride; p2.ln_eps = eps;
+        launch_gemm(p2, epi, tile2, s);
+    } else {
+        launch_gemm(p1, EPI_RESID_F32, tile1, s);
+        launch_layernorm((const float *)dx.p, (int)h, nullptr, 1, (const float *)dg.p, (const float *)dbeta.p, eps, (int)M, (int)h, (half_t *)dxn.p, W2.Kpad, nullptr, 0, s);
+        p2.bias = (const float *)db2.p;
+        launch_gemm(p2, epi, tile2, s);
+    }
+    launch_f16_to_f32((const half_t *)dy16.p, (int)N2, (float *)dy32.p, (int)N2, (int)M, (int)N2, s);
+    int rc = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = -4;
+    else {
+        (void)hipMemcpy(x1_out, dx.p, (size_t)M * h * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(y_out, dy32.p, (size_t)M * N2 * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(w1base);
+    (void)hipFree(w2base);
+    return rc;
+}
+
 int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M, const float * bias, const float * resid,
                        float * y, int epilogue, int tile) {
     return clip_amd_test_gemm_ex(type, w_raw, N, K, x, M, bias, resid, y, epilogue, tile, 0, 1.0f, 0, 0, nullptr);

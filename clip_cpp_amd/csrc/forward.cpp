@@ -243,6 +243,60 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
     return true;
 }
 
+// The same chain with every LayerNorm folded into the GEMMs around it (gemm_common.h; reference ops clip.cpp:1350-1355,1400-1405 and
+// text :1071-1076,1121-1126): 5 launches per layer.  The residual epilogues (out-projection, FFN-down) leave xg = fp16(x gamma_next)
+// in xn and the partial row statistics in `stats`; the q/k/v and FFN-up epilogues apply rstd (acc - mean c) + b'.
+// Precondition: xn = fp16(x * ln1_w of layer 0) and stats = ONE slot per row over all h columns (launch_layernorm_prep / launch_text_embed).
+bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
+                     const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid,
+                     float2 * stats, int stats_stride) {
+    hipStream_t s = ctx->stream;
+    const int dh = h / nh;
+    const float qscale = 1.0f / sqrtf((float)dh);
+    const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    int slots = 1, slotw = h;
+    auto consume = [&](GemmParams & p, const float * c, const float * bf) {
+        p.A = xn; p.lda = h; p.bias = bf; p.ln_c = c; p.ln_stats = stats; p.ln_slots = slots; p.ln_slotw = slotw; p.ln_stride = stats_stride; p.ln_eps = eps;
+    };
+    auto produce = [&](GemmParams & p, const float * gamma_next) {
+        if (!gamma_next) return;                              // last layer: the pooled rows go through the post-LN launch
+        p.xg_out = xn; p.ldxg = h; p.xg_gamma = gamma_next; p.stats_out = stats; p.stats_stride = stats_stride;
+        const bool quant = !p.w16_pre && p.W.wtype != W_F16;
+        slotw = gemm_fold_slotw_for(p.M, p.W.N, p.W.Kpad, quant);
+        slots = h / slotw;
+    };
+    for (size_t li = 0; li < tw.layers.size(); li++) {
+        const DevLayer & l = tw.layers[li];
+        const LayerPanels lp = dequant_layer(ctx, l, rows);
+        GemmParams p;
+        p.M = rows; p.W = l.qkv; p.out = qkv; p.ldc = 3 * h; p.w16_pre = lp.qkv;
+        p.qscale = qscale; p.qcols = h;   // Q = (W_q LN(x) + b_q) / sqrt(d_head): scale after bias (clip.cpp:1363)
+        consume(p, l.qkv_c, l.qkv_bf);
+        gemm(ctx, "gemm_qkv", p, EPI_F16);
+        {
+            const double afl = 4.0 * (double)nseq * nh * (double)max_len * max_len * dh;
+            ProfScope ps(ctx, "attention", nseq * nh, max_len, dh, afl, (double)rows * h * 8);
+            if (!launch_attention(qkv, att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s)) {
+                fprintf(stderr, "clip (hip): attention kernel does not support T=%d d_head=%d\n", max_len, dh);
+                return false;
+            }
+        }
+        GemmParams po;
+        po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x; po.w16_pre = lp.o;
+        produce(po, l.ln2_w);
+        gemm(ctx, "gemm_out", po, EPI_RESID_F32);
+        GemmParams p1;
+        p1.M = rows; p1.W = l.ff1; p1.out = mid; p1.ldc = ff; p1.w16_pre = lp.ff1;
+        consume(p1, l.ff1_c, l.ff1_bf);
+        gemm(ctx, "gemm_ffn_up", p1, act);
+        GemmParams p2;
+        p2.A = mid; p2.lda = ff; p2.M = rows; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = x; p2.ldc = h; p2.resid = x; p2.w16_pre = lp.ff2;
+        produce(p2, li + 1 < tw.layers.size() ? tw.layers[li + 1].ln1_w : nullptr);
+        gemm(ctx, "gemm_ffn_down", p2, EPI_RESID_F32);
+    }
+    return true;
+}
+
 bool check_device(clip_ctx * ctx, const char * who) {
     if (!ctx || ctx->device < 0) {
         fprintf(stderr, "%s: no HIP device bound to this context — the encoders have no CPU fallback\n", who);
@@ -404,8 +458,11 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
         const int Bc = std::min(chunk, B - b0);
         const int rows = Bc * T;
         Carver sizer(nullptr);
+        const int st_stride = (rows + 63) & ~63;               // LayerNorm-fold statistics: [h / 32 slots][st_stride rows] float2
+        float2 * stats = nullptr;
         auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& col,
                          half_t *& pooled, float *& emb) {
+            stats = c.take<float2>((size_t)(h / 32) * st_stride);
             x = c.take<float>((size_t)rows * h);
             xn = c.take<half_t>((size_t)rows * h);
             qkv = c.take<half_t>((size_t)rows * 3 * h);
@@ -434,13 +491,19 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
         pp.Np = Np; pp.T = T; pp.pos = V.pos;
         gemm(ctx, "gemm_patch", pp, EPI_PATCH_F32);
         launch_cls_rows(x, V.class_embd, V.pos, Bc, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
+        const bool skinny = layers_fit_skinny(V, rows, h, ff);
+        const bool fold = !skinny && ctx->ln_fold && !V.layers.empty();
         {
-            ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 8);
-            launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);  // pre-LN (:1334-1339)
+            ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
+            if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
+                launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, xn, h, stats, s);
+            else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
         }
-        if (layers_fit_skinny(V, rows, h, ff)) {
+        if (skinny) {
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, qkv, att, mid)) return false;
+        } else if (fold) {
+            if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid, stats, st_stride)) return false;
         } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid)) return false;
         // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
         launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, pooled, h, nullptr, 0, s);
@@ -477,8 +540,11 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         }
         max_len = std::max(max_len, len);
     }
+    const int st_stride = (rows + 63) & ~63;                   // LayerNorm-fold statistics: [h / 32 slots][st_stride rows] float2
+    float2 * stats = nullptr;
     auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& pooled,
                      float *& emb, int *& seq, int *& last) {
+        stats = c.take<float2>((size_t)(h / 32) * st_stride);
         x = c.take<float>((size_t)rows * h);
         xn = c.take<half_t>((size_t)rows * h);
         qkv = c.take<half_t>((size_t)rows * 3 * h);
@@ -525,10 +591,16 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         mr.busy[sl] = true;
     }
     auto launch_all = [&]() -> bool {
-        launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
-        if (layers_fit_skinny(Tw, rows, h, ff)) {
+        const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
+        const bool fold = !skinny && ctx->ln_fold && !Tw.layers.empty();
+        if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
+            launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats);
+        else launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
+        if (skinny) {
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, qkv, att, mid)) return false;
+        } else if (fold) {
+            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride)) return false;
         } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
         // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
         launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);

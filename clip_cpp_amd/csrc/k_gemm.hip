@@ -459,6 +459,21 @@ void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
 int gemm_tile_for(int M, int N, int Kpad, bool quantised) { return pick_tile(M, N, Kpad, quantised); }
 
+// LayerNorm fold: columns per statistics slot written by the residual epilogue of the kernel behind a tile code (fold_slotw<TN>() of
+// gemm_common.h: 64 where a wave spans >= 64 columns — the BN = 128 tiles of this file, k_gemm8.hip, k_gemm4.hip —, else 32)
+int gemm_fold_slotw(int tile) {
+    tile %= 1000000;
+    if (gemm_tile_is_ring(tile)) return 32;                        // 2 x 2 and 4 x 1 waves over 64 / 128 columns: 32 per wave
+    if (gemm_tile_uses_panel(tile)) return 64;                     // (also when the panel is missing: the fallback is the 160 x 128 tile)
+    return tile % 1000 == 64 ? 32 : 64;
+}
+// the rows past the whole rounds of a split launch (tile codes 258 / 260): in fold mode they must leave the same slot width as the head
+static int fold_rest_tile(int M, int N, int Kpad, bool quantised) {
+    const int t = pick_tile(M, N, Kpad, quantised);
+    return gemm_fold_slotw(t) == 64 && t % 1000 != 258 && t % 1000 != 260 ? t : 64128;
+}
+int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised) { return gemm_fold_slotw(pick_tile(M, N, Kpad, quantised)); }
+
 // Split-K factor for a BM = 64 tile grid (small-M problems: batch 1 / 32, single texts), fitted with
 // scripts/gemm_bench.py (profiles/r01_gemm_splitk.txt): a K-step costs ~0.5 us of serial latency, the fix-up ~3 us, so
 // splitting pays when the K loop is long — ksplit ~ sqrt(nk / 1.5) (12 steps -> 3, 48 -> 6) — and, once the grid already
@@ -508,8 +523,12 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
             rest.A = p.A + (size_t)m1 * p.lda;
             rest.out = (char *)p.out + (size_t)m1 * p.ldc * (f16_out ? sizeof(half_t) : sizeof(float));
             if (p.resid) rest.resid = p.resid + (size_t)m1 * p.ldc;
+            // LayerNorm fold: the statistics are [slot][row] (row offset = pointer offset), xg is row-major
+            if (p.ln_stats) rest.ln_stats = p.ln_stats + m1;
+            if (p.stats_out) rest.stats_out = p.stats_out + m1;
+            if (p.xg_out) rest.xg_out = p.xg_out + (size_t)m1 * p.ldxg;
             launch_gemm(head, epilogue, tile, stream);
-            launch_gemm(rest, epilogue, 0, stream);
+            launch_gemm(rest, epilogue, p.xg_out ? fold_rest_tile(rest.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16) : 0, stream);
             return;
         }
     }

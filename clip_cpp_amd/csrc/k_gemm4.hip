@@ -241,8 +241,11 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
             raw_barrier4();                            // every wave is done with the ring: it becomes the staging area
             half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
             typedef f4 half_acc_t[4][TM];
-            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane);
-            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane);
+            LnRows<TM> lnr;                            // LayerNorm folded into this GEMM: the row statistics once for both column halves
+            const bool ln = p.ln_c != nullptr;
+            if (ln) ln_rows_load<TM>(lnr, p, mb, frow, fgrp);
+            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane, ln ? &lnr : nullptr);
+            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane, ln ? &lnr : nullptr);
             done = true;
         }
     }

@@ -327,6 +327,27 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
 #endif
 #pragma unroll
     for (int s = 0; s < NS - 1; s++) RING_ISSUE(s, (s < last ? s : last));
+    // LayerNorm folded into this GEMM (gemm_common.h): the row statistics and the c vector are fetched behind the prologue requests
+    // and waited for before the loop (their wait also lands the prologue tiles), so the counted waits of the loop see only its own requests
+    constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
+    const bool ln = LNE && p.ln_c != nullptr && ksplit == 1;
+    f4 c_pre[TN];
+    LnRows<TM> lnr;
+#pragma unroll
+    for (int a = 0; a < TN; a++) c_pre[a] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < TM; b++) { lnr.mu[b] = 0.f; lnr.rstd[b] = 1.f; }
+    if constexpr (LNE) {
+        if (ln) {
+#pragma unroll
+            for (int a = 0; a < TN; a++) {
+                int n = nb_w + a * 16 + fgrp * 4;
+                n = n < p.W.N ? n : 0;
+                c_pre[a] = *(const f4 *)(p.ln_c + n);
+            }
+            ln_rows_load<TM>(lnr, p, mb_w, frow, fgrp);
+        }
+    }
     int st = 0;                // stage of tile kt
     int sq = NS - 1;           // stage the next request goes to
     for (int kt = 0; kt < nk; kt++) {
@@ -402,7 +423,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
                 }
         }
     }
-    if (ksplit == 1) gemm_epilogue_pre<EPI, TN, TM>(p, acc, bias_pre, resid_pre, nb_w, mb_w, frow, fgrp);
+    if (ksplit == 1) gemm_epilogue_pre<EPI, TN, TM>(p, acc, bias_pre, resid_pre, nb_w, mb_w, frow, fgrp, ln, c_pre, lnr);
     else gemm_epilogue<EPI, TN, TM>(p, acc, nb_w, mb_w, frow, fgrp);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {

@@ -84,6 +84,85 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float * __restrict
     }
 }
 
+// Entry of the LayerNorm-folded layer chain (gemm_common.h): for every row, y = LayerNorm(x) w + b (w == nullptr: y = x), written to
+// out32 (may alias x), plus what the first q/k/v GEMM consumes: xg = fp16(y gamma_next) and the whole-row statistics (sum, sum of
+// squared deviations from the mean) of y as ONE slot of width h.  The row lives in registers: every pass is a register pass.
+template <int NV>
+__device__ __forceinline__ void row_fold_prep(const f4 (&y)[NV], int h, int lane, const float * __restrict__ gnext, half_t * __restrict__ xg_row,
+                                              float2 * __restrict__ stat) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+        if ((i * 64 + lane) * 4 < h) s += (y[i][0] + y[i][1]) + (y[i][2] + y[i][3]);
+    s = wave_sum(s);
+    const float mean = s / (float)h;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+        if ((i * 64 + lane) * 4 < h) {
+            const f4 d = y[i] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    q = wave_sum(q);
+    if (lane == 0) *stat = make_float2(s, q);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < h) {
+            const f4 g = y[i] * *(const f4 *)(gnext + c);
+            const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]}, hi = (h2){(_Float16)g[2], (_Float16)g[3]};
+            *(uint2 *)(xg_row + c) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+        }
+    }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) layernorm_prep_kernel(const float * x, int ldx, const float * __restrict__ w, const float * __restrict__ b,
+                                                             float eps, int rows, int h, float * out32, int ld32,
+                                                             const float * __restrict__ gnext, half_t * __restrict__ xg, int ldxg,
+                                                             float2 * __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float * xr = x + (size_t)r * ldx;
+    f4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < h) {
+            v[i] = *(const f4 *)(xr + c);
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else {
+            v[i] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (w) {        // same arithmetic as layernorm_kernel (two-pass mean / variance, y = (x - mean) scale w + b)
+        const float mean = wave_sum(sum) / (float)h;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < h) {
+                v[i] = v[i] - mean;
+                sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            }
+        }
+        const float var = wave_sum(sq) / (float)h;
+        const float scale = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < h) {
+                const f4 ww = *(const f4 *)(w + c), bb = *(const f4 *)(b + c);
+                v[i] = (v[i] * scale) * ww + bb;
+                if (out32) *(f4 *)(out32 + (size_t)r * ld32 + c) = v[i];
+            }
+        }
+    }
+    row_fold_prep<NV>(v, h, lane, gnext, xg + (size_t)r * ldxg, stats + r);
+}
+
 // ---------------------------------------------------------------------------------------------
 // im2col (fp16) for the stride-P, no-padding patch convolution: col[(b,oy,ox)][(c,ky,kx)] =
 // fp16(img[b][oy*P+ky][ox*P+kx][c]); two k's per thread, padded columns are zero.
@@ -206,10 +285,17 @@ __device__ float dequant_elem(const uint8_t * row, int type, int k) {
     return 0.f;
 }
 
-__global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restrict__ ids, const int * __restrict__ seq_start, int nseq,
+// One wave per row (4 rows per workgroup), the row in registers; with gnext != nullptr the kernel is also the entry of the
+// LayerNorm-folded layer chain (row_fold_prep): xg = fp16(x gamma_next) and the whole-row statistics for the first q/k/v GEMM.
+template <int NV>
+__global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restrict__ ids, const int * __restrict__ seq_start, int nseq, int rows,
                                                          const uint8_t * __restrict__ tok, int tok_type, size_t tok_row_bytes,
-                                                         const float * __restrict__ pos, int h, float * __restrict__ x) {
-    const int row = blockIdx.x;
+                                                         const float * __restrict__ pos, int h, float * __restrict__ x,
+                                                         const float * __restrict__ gnext, half_t * __restrict__ xg, int ldxg,
+                                                         float2 * __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
     // position within its sequence: binary search seq_start (nseq+1 entries, ascending)
     int lo = 0, hi = nseq;
     while (hi - lo > 1) {
@@ -218,8 +304,20 @@ __global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restr
     }
     const int t = row - seq_start[lo];
     const uint8_t * trow = tok + (size_t)ids[row] * tok_row_bytes;
-    for (int c = threadIdx.x; c < h; c += 256)
-        x[(size_t)row * h + c] = pos[(size_t)t * h + c] + dequant_elem(trow, tok_type, c);
+    f4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < h) {
+            const f4 pe = *(const f4 *)(pos + (size_t)t * h + c);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[i][e] = pe[e] + dequant_elem(trow, tok_type, c + e);
+            *(f4 *)(x + (size_t)row * h + c) = v[i];
+        } else {
+            v[i] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (gnext) row_fold_prep<NV>(v, h, lane, gnext, xg + (size_t)row * ldxg, stats + row);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,10 +468,34 @@ static size_t raw_row_bytes(int type, int k) {
 }
 
 void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw, int tok_type,
-                       const float * pos, int h, float * x, hipStream_t stream) {
+                       const float * pos, int h, float * x, hipStream_t stream, const float * gamma_next, half_t * xg, int ldxg, float2 * stats) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(text_embed_kernel, dim3(rows), dim3(256), 0, stream, ids, seq_start, nseq, (const uint8_t *)tok_raw,
-                       tok_type, raw_row_bytes(tok_type, h), pos, h, x);
+    const dim3 grid((rows + 3) / 4), block(256);
+#define CLIPAMD_TE(NV)                                                                                                              \
+    hipLaunchKernelGGL((text_embed_kernel<NV>), grid, block, 0, stream, ids, seq_start, nseq, rows, (const uint8_t *)tok_raw, tok_type, \
+                       raw_row_bytes(tok_type, h), pos, h, x, gamma_next, xg, ldxg, stats)
+    if (h <= 256) { CLIPAMD_TE(1); }
+    else if (h <= 512) { CLIPAMD_TE(2); }
+    else if (h <= 768) { CLIPAMD_TE(3); }
+    else if (h <= 1024) { CLIPAMD_TE(4); }
+    else if (h <= 1280) { CLIPAMD_TE(5); }
+    else { CLIPAMD_TE(8); }   // h <= 2048
+#undef CLIPAMD_TE
+}
+
+void launch_layernorm_prep(const float * x, int ldx, const float * w, const float * b, float eps, int rows, int h, float * out32, int ld32,
+                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream) {
+    if (rows <= 0) return;
+    const dim3 grid((rows + 3) / 4), block(256);
+#define CLIPAMD_LNP(NV)                                                                                                             \
+    hipLaunchKernelGGL((layernorm_prep_kernel<NV>), grid, block, 0, stream, x, ldx, w, b, eps, rows, h, out32, ld32, gamma_next, xg, ldxg, stats)
+    if (h <= 256) { CLIPAMD_LNP(1); }
+    else if (h <= 512) { CLIPAMD_LNP(2); }
+    else if (h <= 768) { CLIPAMD_LNP(3); }
+    else if (h <= 1024) { CLIPAMD_LNP(4); }
+    else if (h <= 1280) { CLIPAMD_LNP(5); }
+    else { CLIPAMD_LNP(8); }   // h <= 2048
+#undef CLIPAMD_LNP
 }
 
 void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream) {

@@ -87,6 +87,23 @@ struct GemmParams {
     half_t * w16_scratch = nullptr;
     size_t w16_scratch_halfs = 0;
     int debug = 0;   // ablation switches, honoured only by -DCLIPAMD_ABLATION tuning builds (scripts/build_variant.sh): 1 skip tile loads, 2 skip MFMAs, 4 skip W dequant-store
+    // ---- LayerNorm folded into the GEMMs around it (reference clip.cpp:1350-1355,1400-1405; text :1071-1076,1121-1126) ----
+    // y = W LN(x) + b with LN(x) = (x - mean) rstd gamma + beta  ==  rstd (W (x gamma) - mean c) + b',  c_n = sum_k gamma_k W_nk,
+    // b'_n = sum_k beta_k W_nk + b_n (both precomputed at load from the weights as the kernels dequantise them: k_fold.hip).
+    // Consumer (EPI_F16 / EPI_GELU_F16 / EPI_QGELU_F16 with ln_c != null): A holds fp16(x gamma), bias holds b', and the epilogue
+    // applies rstd_m (acc - mean_m c_n) + b'_n before the Q scale / activation; (mean, rstd) of row m come from ln_stats.
+    const float * ln_c = nullptr;          // [N]
+    const float2 * ln_stats = nullptr;     // [ln_slots][ln_stride]: (sum, sum of squared deviations from the slot mean) of row m over
+    int ln_slots = 0, ln_slotw = 0;        //   columns [slot * ln_slotw, (slot + 1) * ln_slotw) of the f32 residual stream
+    int ln_stride = 0;
+    float ln_eps = 0.f;
+    // Producer (EPI_RESID_F32 with xg_out != null): besides out = resid + acc + bias the epilogue writes the next GEMM's operand
+    // xg_out[m][n] = fp16(out[m][n] * xg_gamma[n]) and the partial row statistics stats_out[n / w][m], w = gemm_fold_slotw(tile) columns per slot.
+    half_t * xg_out = nullptr;
+    int ldxg = 0;
+    const float * xg_gamma = nullptr;
+    float2 * stats_out = nullptr;
+    int stats_stride = 0;
 };
 
 // tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64 / 65;
@@ -112,6 +129,15 @@ void launch_gemm4(const GemmParams & p, int epilogue, hipStream_t stream);
 // dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)
 struct DequantJobs { DevWeight W[4]; half_t * out[4]; int blk_end[4]; int n = 0; };
 void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, hipStream_t stream);
+
+// LayerNorm fold (gemm_common.h): columns per statistics slot that the residual epilogue of the kernel behind `tile` writes (64, or
+// 32 for the ring kernel and the BN = 64 tiles whose waves span 32 columns), and the same for the tile launch_gemm's heuristic picks
+// for a shape in fold mode (the rows past the whole rounds of a split launch are then kept on a 64-column kernel).
+int gemm_fold_slotw(int tile);
+int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised);
+// k_fold.hip (once per model load): c[n] = sum_k gamma[k] W[n][k], b_out[n] = sum_k beta[k] W[n][k] + bias[n], W as the GEMMs dequantise it
+void launch_fold_vectors(const DevWeight & W, const float * gamma, const float * beta, const float * bias, float * c_out, float * b_out,
+                         hipStream_t stream);
 
 // k_skinny.hip: latency-oriented weight GEMM for small M (one image, one text; the layers use it up to 64 rows): N / 16 x ceil(M / 16)
 // workgroups, weights dequantised in registers straight from the planes, intra-workgroup split-K, optional LayerNorm fused on the A operand (A = LN(x32) with row
@@ -148,6 +174,12 @@ void launch_row_stats(const float * x, int ldx, int rows, int h, float2 * stats,
 // CLS rows b*T); out16/out32 may be null.
 void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_mul, const float * w, const float * b, float eps,
                       int rows, int h, half_t * out16, int ld16, float * out32, int ld32, hipStream_t stream);
+// Entry of the LayerNorm-folded layer chain (gemm_common.h): what the first layer's q/k/v GEMM needs from the rows of the residual
+// stream y — xg[r] = fp16(y[r] * gamma_next) and the whole-row statistics stats[r] = (sum, sum of squared deviations): ONE slot of
+// width h (GemmParams::ln_slots = 1, ln_slotw = h).  launch_layernorm_prep: y = LayerNorm(x) w + b (the vision tower's pre-LN,
+// reference clip.cpp:1334-1339) written to out32 in the same launch; launch_text_embed with xg != null: y = the embedded rows.
+void launch_layernorm_prep(const float * x, int ldx, const float * w, const float * b, float eps, int rows, int h, float * out32, int ld32,
+                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream);
 
 // Multi-head self-attention softmax(QK^T)V (reference clip.cpp:1382-1388; causal for text :1101).
 // qkv: [rows][3h] fp16 with Q pre-scaled; sequences given by seq_start[nseq+1] (device) or, when
@@ -165,7 +197,8 @@ void launch_cls_rows(float * x, const float * class_embd, const float * pos, int
 // text embedding: x[r][:] = dequant(token_embd[ids[r]]) + pos[r - seq_start(r)]  (reference clip.cpp:1059-1061)
 // tok_raw is the token_embd tensor in its ggml block layout (type = ggml type id).
 void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw,
-                       int tok_type, const float * pos, int h, float * x, hipStream_t stream);
+                       int tok_type, const float * pos, int h, float * x, hipStream_t stream,
+                       const float * gamma_next = nullptr, half_t * xg = nullptr, int ldxg = 0, float2 * stats = nullptr);
 
 // out[r][:] = v[r][:] / ||v[r]||_2  (reference clip.cpp:1446-1455) or plain copy when !normalize
 void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream);

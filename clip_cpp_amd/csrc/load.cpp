@@ -165,6 +165,12 @@ struct Loader {
         return true;
     }
 
+    // n zero-filled floats the device fills after the upload (LayerNorm fold vectors, k_fold.hip)
+    bool zeros_f32(const float ** slot, int64_t n) {
+        fix((const void **)slot, st.alloc((size_t)n * 4));
+        return true;
+    }
+
     // 2-D embedding table dequantised to f32 [rows][k]
     bool table_f32(const std::string & name, const float ** slot, int64_t k, int64_t rows) {
         const GgufTensorInfo * t = need(name);
@@ -237,6 +243,8 @@ struct Loader {
             if (!linear({nm("ffn_up", "weight")}, l.ff2, ff, h) || !vec_f32({nm("ffn_up", "bias")}, &l.ff2_b, h)) return false;
             if (!vec_f32({nm("ln1", "weight")}, &l.ln1_w, h) || !vec_f32({nm("ln1", "bias")}, &l.ln1_b, h)) return false;
             if (!vec_f32({nm("ln2", "weight")}, &l.ln2_w, h) || !vec_f32({nm("ln2", "bias")}, &l.ln2_b, h)) return false;
+            zeros_f32(&l.qkv_c, 3 * (int64_t)h); zeros_f32(&l.qkv_bf, 3 * (int64_t)h);
+            zeros_f32(&l.ff1_c, ff); zeros_f32(&l.ff1_bf, ff);
         }
         return true;
     }
@@ -244,7 +252,7 @@ struct Loader {
 
 // File "<dir>/<basename>.<key>.hbm" = 32-byte header {magic, version, key, image bytes} + the HBM image.
 struct WeightCache {
-    static constexpr uint32_t kVersion = 1;    // bump when the device layout of any tensor changes
+    static constexpr uint32_t kVersion = 2;    // bump when the device layout of any tensor changes (2: LayerNorm fold vectors)
     bool enabled = false, readable = false;
     std::string path;
     uint64_t key = 0, image_bytes = 0;
@@ -524,6 +532,16 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     if (hipMemcpy(ctx->weights_base, LL.st.buf.data(), LL.st.size, hipMemcpyHostToDevice) != hipSuccess) return fail("weight upload failed");
     if (!ctx->weights_from_cache) cache.write_image(LL.st.buf);
     for (const Fix & f : LL.fixes) *f.slot = (const uint8_t *)ctx->weights_base + f.off;
+    {   // LayerNorm fold vectors (k_fold.hip): computed on the device from the weights as the GEMM kernels dequantise them
+        for (DevTower * tw : {&ctx->vision, &ctx->text})
+            for (DevLayer & l : tw->layers) {
+                launch_fold_vectors(l.qkv, l.ln1_w, l.ln1_b, l.qkv_b, (float *)l.qkv_c, (float *)l.qkv_bf, ctx->stream);
+                launch_fold_vectors(l.ff1, l.ln2_w, l.ln2_b, l.ff1_b, (float *)l.ff1_c, (float *)l.ff1_bf, ctx->stream);
+            }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail("LayerNorm fold vectors: kernel failed");
+        const char * e = getenv("CLIP_AMD_LNFOLD");
+        ctx->ln_fold = !(e && e[0] == '0');
+    }
     if (verbosity >= 1) printf("\n%s: %zu MB of HBM allocated for weights on device %d\n", "clip_model_load", ctx->weights_bytes / 1024 / 1024, device);
     return ctx;
 }

@@ -22,6 +22,9 @@ struct DevLayer {
     DevWeight qkv, o, ff1, ff2;
     const float *qkv_b = nullptr, *o_b = nullptr, *ff1_b = nullptr, *ff2_b = nullptr;
     const float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+    // LayerNorm fold (gemm_common.h): c_n = sum_k gamma_k W_nk and b'_n = sum_k beta_k W_nk + b_n of (LN1, q/k/v) and (LN2, FFN-up),
+    // filled on the device right after the upload (k_fold.hip)
+    const float *qkv_c = nullptr, *qkv_bf = nullptr, *ff1_c = nullptr, *ff1_bf = nullptr;
 };
 
 struct DevTower {
@@ -124,6 +127,7 @@ struct clip_ctx {
     // LayerNorm partial statistics of the small-M path (k_skinny.hip): two [128 slots][128 rows] float2 buffers, written by the
     // residual epilogues and read by the LayerNorm-fused projections of the next sub-layer
     float2 * sk_stats = nullptr;
+    bool ln_fold = true;             // LayerNorm folded into the GEMM epilogues for > 64 rows (CLIP_AMD_LNFOLD=0: the two-launch form, for A/B)
     // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
     clipamd::half_t * w16_panel = nullptr;
     size_t w16_panel_halfs = 0;

@@ -124,6 +124,15 @@ int clip_amd_test_gemm(int type, const void * w_raw, int64_t N, int64_t K, const
 int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, const float * x, int64_t M,
                           const float * bias, const float * resid, float * y, int epilogue, int tile,
                           int qcols, float qscale, int Np, int T, const float * pos);
+/* LayerNorm fold A/B (the LayerNorm launches of reference clip.cpp:1350-1355,1400-1405 folded into the GEMM epilogues around them):
+ *   x1 = resid + a . W1^T + b1                       [M][h]   W1: [h][K1]  (residual epilogue)
+ *   y  = epi2( LN(x1; gamma, beta, eps) . W2^T + b2 )  [M][N2]  W2: [N2][h]  (epi2: 1 f16 (+ qcols / qscale), 2 gelu, 3 quick-gelu)
+ * fold = 0: three launches (GEMM, LayerNorm kernel, GEMM); fold = 1: two launches — the residual epilogue also writes fp16(x1 gamma) and
+ * partial row statistics, the second GEMM's epilogue applies rstd (acc - mean c) + b'.  tile1 / tile2 as `tile` of clip_amd_test_gemm.
+ * x1_out [M][h] f32, y_out [M][N2] (fp16 widened).  h % 64 == 0. */
+int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, const void * w2_raw, int64_t N2, const float * a, int64_t M,
+                         const float * b1, const float * resid, const float * gamma, const float * beta, float eps, const float * b2,
+                         int epi2, int tile1, int tile2, int fold, int qcols, float qscale, float * x1_out, float * y_out);
 /* The tile the heuristic of launch_gemm picks for an [M][K] x [N][K]^T problem (pure host arithmetic, no device needed):
  * BM * 1000 + BN; BM = 65: the mid-M ring kernel on 64-row tiles (k_gemm_ring.hip), BN = 256 / 258-260: the large-M panel kernels. */
 int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised);

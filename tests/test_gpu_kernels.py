@@ -512,3 +512,107 @@ def test_skinny_layernorm_fused_projection(L, tname, M, N, K, epi):
     assert bad.size == 0, (len(bad), np.abs(y - want).max())
     rel = np.linalg.norm(y - want) / np.linalg.norm(want)
     assert rel < 1e-3, rel
+
+
+# ---- LayerNorm folded into the GEMM epilogues (gemm_common.h: resid_fold_tail / ln_rows_load; reference clip.cpp:1350-1355,1400-1405) ----
+def run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, tile1, tile2, fold, qcols=0, qscale=1.0, eps=1e-5):
+    M = A.shape[0]
+    x1 = np.full((M, h), np.nan, dtype=np.float32)
+    y = np.full((M, N2), np.nan, dtype=np.float32)
+    rc = L.clip_amd_test_lnfold(tid, raw1.ctypes.data_as(C.c_void_p), h, K1, raw2.ctypes.data_as(C.c_void_p), N2, _fp(A), M, _fp(b1), _fp(resid),
+                                _fp(g), _fp(beta), eps, _fp(b2), epi2, tile1, tile2, fold, qcols, qscale, _fp(x1), _fp(y))
+    assert rc == 0, "clip_amd_test_lnfold rc=%d" % rc
+    return x1, y
+
+
+def _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=0.3):
+    tid = ref.GGML_TYPES[tname]
+    raw1 = ref.quantize(tid, _weights(rng, h, K1))
+    W2 = _weights(rng, N2, h)
+    raw2 = ref.quantize(tid, W2)
+    Wd2 = ref.dequantize(tid, raw2, N2, h).astype(np.float64)
+    A = rng.standard_normal((M, K1)).astype(np.float32)
+    resid = (rng.standard_normal((M, h)) * 2.5 + mean_shift).astype(np.float32)
+    resid[:, rng.integers(0, h, size=2)] *= 20.0            # outlier channels of the residual stream
+    b1 = (rng.standard_normal(h) * 0.1).astype(np.float32)
+    g = (1 + rng.standard_normal(h) * 0.2).astype(np.float32)
+    beta = (rng.standard_normal(h) * 0.1).astype(np.float32)
+    b2 = (rng.standard_normal(N2) * 0.1).astype(np.float32)
+    return tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2
+
+
+def _lnfold_reference(x1, g, beta, Wd2, b2, epi2, qcols, qscale, eps=1e-5):
+    """float64 LayerNorm of the GPU's own f32 residual rows -> exact product; bound = fp16 rounding of the folded operand x * gamma."""
+    x = x1.astype(np.float64)
+    mu = x.mean(1, keepdims=True)
+    var = ((x - mu) ** 2).mean(1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    ln = (x - mu) * rstd * g + beta
+    lin = ln @ Wd2.T + b2
+    want = {1: lin, 2: gelu_tanh(lin), 3: gelu_quick(lin)}[epi2].copy()
+    want[:, :qcols] *= qscale
+    # |sum_k W_nk e_k| <= 2^-11 sum_k |x_k gamma_k W_nk|, scaled by rstd; activations are 1.13-Lipschitz; + the output's own fp16 rounding
+    pre = rstd * (2.0 ** -11) * (np.abs(x * g) @ np.abs(Wd2).T)
+    bound = 1.2 * 1.05 * pre + np.abs(want) * 2.0 ** -10 + 2e-4
+    return want, bound, lin
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "f16", "q5_1"])
+@pytest.mark.parametrize("tile1,tile2,epi2", [(64064, 64064, 1), (64128, 128064, 2), (128128, 160128, 3), (160128, 192128, 1), (192128, 128128, 2),
+                                              (65064, 65128, 1), (65128, 65064, 3), (3065128, 2064064, 2), (160256, 160256, 1), (256259, 256259, 3),
+                                              (256256, 128256, 2), (0, 0, 1)])
+def test_lnfold_vs_float64_and_two_launch_form(L, tname, tile1, tile2, epi2):
+    """The folded form (residual epilogue emits fp16(x gamma) + partial statistics, consumer epilogue applies rstd (acc - mean c) + b')
+    through every producer / consumer kernel: (a) the f32 residual rows are bit-identical to the unfolded launch, (b) the output is within
+    the rigorous fp16-operand bound of the float64 LayerNorm + product, (c) folded and three-launch outputs agree to 2 fp16 ulp."""
+    rng = np.random.default_rng(7 + epi2)
+    M, h, K1, N2 = 203, 320, 192, 448
+    tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2)
+    qc, qs = (128, 0.125) if epi2 == 1 else (0, 1.0)
+    x1a, ya = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, tile1, tile2, 0, qc, qs)
+    x1b, yb = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, tile1, tile2, 1, qc, qs)
+    if tile1 // 1000000 <= 1:     # (split-K re-associates the fp32 sums identically in both runs too: same kernel, same order)
+        assert np.array_equal(x1a, x1b), _diff_report(x1a, x1b)
+    want, bound, lin = _lnfold_reference(x1b, g, beta, Wd2, b2, epi2, qc, qs)
+    err = np.abs(yb - want)
+    bad = np.argwhere(err > bound)
+    assert np.all(np.isfinite(yb))
+    assert bad.size == 0, "%d/%d bad, first %s got %g want %g bound %g; max err %g" % (
+        len(bad), yb.size, bad[0], yb[tuple(bad[0])], want[tuple(bad[0])], bound[tuple(bad[0])], err.max())
+    # A/B: 2 fp16 ulp of max(|y|, row rms) (an output near zero keeps the absolute error of its row)
+    scale = np.maximum(np.abs(ya), np.sqrt((ya.astype(np.float64) ** 2).mean(1, keepdims=True)))
+    ab = np.abs(yb - ya) / (scale * 2.0 ** -10)
+    assert ab.max() <= 2.0, "A/B max %.2f ulp at %s" % (ab.max(), np.unravel_index(ab.argmax(), ab.shape))
+    rel = np.linalg.norm(yb - want) / np.linalg.norm(want)
+    rel0 = np.linalg.norm(ya - want) / np.linalg.norm(want)
+    assert rel < 1.5 * rel0 + 1e-4, (rel, rel0)          # not noisier than the LayerNorm-kernel form
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "f16"])
+def test_lnfold_is_bitwise_independent_of_the_producer_and_consumer_kernels(L, tname):
+    """Statistics slots are 64 columns wide out of the wide kernels and 32 out of the ring / BN = 64 tiles; the consumer merges the
+    32-column pairs first, which reproduces the 64-column slot exactly -> the folded output does not depend on tile shapes."""
+    rng = np.random.default_rng(11)
+    M, h, K1, N2 = 150, 384, 128, 320
+    tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2)
+    base = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, 64128, 64128, 1)[1]
+    for t1, t2 in [(64064, 64128), (65064, 64128), (65128, 128128), (160128, 65064), (192128, 65128), (160256, 160128), (256259, 256256), (128064, 128064)]:
+        y = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, t1, t2, 1)[1]
+        assert np.array_equal(base, y), "tiles (%d, %d): %s" % (t1, t2, _diff_report(base, y))
+
+
+@pytest.mark.parametrize("tname,M,h,K1,N2,epi2", [("q4_0", 1600, 768, 768, 2304, 1), ("q4_0", 1600, 768, 3072, 3072, 3), ("f16", 1300, 1024, 1024, 3072, 1),
+                                                  ("q8_0", 2500, 512, 2048, 2048, 2), ("q5_1", 771, 1280, 1280, 1280, 2)])
+def test_lnfold_model_shapes_heuristic_tiles(L, tname, M, h, K1, N2, epi2):
+    """Model widths through the tiles the heuristic picks (ring kernel, 160 x 128, split-K), row mean up to 2 sigma away from zero:
+    the fold rounds x gamma to fp16 BEFORE the mean is removed, so its error bound grows with |mean| / sigma — still inside the rigorous bound."""
+    rng = np.random.default_rng(M + h)
+    tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=5.0)
+    qc, qs = (h, 0.125) if epi2 == 1 else (0, 1.0)
+    x1b, yb = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, 0, 0, 1, qc, qs)
+    want, bound, lin = _lnfold_reference(x1b, g, beta, Wd2, b2, epi2, qc, qs)
+    err = np.abs(yb - want)
+    bad = np.argwhere(err > bound)
+    assert bad.size == 0, "%d/%d bad, max err %g" % (len(bad), yb.size, err.max())
+    rel = np.linalg.norm(yb - want) / np.linalg.norm(want)
+    assert rel < 2e-3, rel

@@ -200,6 +200,34 @@ def test_full_size_properties_b32_q4_0_batch256(gpu, fixture_cache):
     assert np.all(one_minus_cos(sub32, full[:32]) <= 1e-6)
 
 
+@pytest.mark.parametrize("config,ftype,n_img", [("b32", "q4_0", 40), ("b32", "f16", 6), ("tiny14", "q5_1", 9)])
+def test_layernorm_fold_matches_the_layernorm_kernel_form_end_to_end(gpu, fixture_cache, monkeypatch, config, ftype, n_img):
+    """Above 64 rows the layers run with every LayerNorm folded into the GEMM epilogues (5 launches per layer; gemm_common.h).
+    CLIP_AMD_LNFOLD=0 keeps the LayerNorm launches: both forms of BOTH towers must agree to fp16-activation rounding
+    (1 - cos <= 1e-6, elements to 3e-4), and the folded form is the default."""
+    p = fixtures.cached_model(fixture_cache, config, ftype)
+    S = 224 if config == "b32" else 28
+    imgs = fixtures.synthetic_images(n_img, S, seed=77)
+    texts = _ragged_text_batch(24, fixtures.CONFIGS[config]["t"]["npos"], seed=3)
+    clip = gpu.Clip(p, device=0)
+    got_i, got_t = clip.encode_images(imgs), clip.encode_texts(texts)
+    clip.profile(True)
+    clip.encode_images(imgs)
+    rep = clip.profile_report(reset=True)
+    clip.close()
+    ln_launches = sum(v["launches"] for k, v in rep.items() if k.startswith("layernorm"))
+    assert ln_launches <= 1, rep.keys()              # only the pre-LN (+ fold entry) launch is tagged; the post-LN is part of the pooling tail
+    monkeypatch.setenv("CLIP_AMD_LNFOLD", "0")
+    clip0 = gpu.Clip(p, device=0)
+    ref_i, ref_t = clip0.encode_images(imgs), clip0.encode_texts(texts)
+    clip0.close()
+    monkeypatch.delenv("CLIP_AMD_LNFOLD")
+    assert np.all(one_minus_cos(got_i, ref_i) <= 1e-6), one_minus_cos(got_i, ref_i).max()
+    assert np.all(one_minus_cos(got_t, ref_t) <= 1e-6), one_minus_cos(got_t, ref_t).max()
+    np.testing.assert_allclose(got_i, ref_i, atol=3e-4)
+    np.testing.assert_allclose(got_t, ref_t, atol=3e-4)
+
+
 @pytest.mark.parametrize("ftype", ["f16", "q4_0"])
 def test_336px_geometry_t577(gpu, fixture_cache, ftype):
     """ViT-L/14@336 geometry (T = 577 tokens, d_head 64): the long-sequence attention instantiation (swizzled K, 155 KB LDS)."""
