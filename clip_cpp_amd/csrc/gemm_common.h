@@ -142,107 +142,127 @@ __device__ __forceinline__ float gelu_quick(float x) { return x * __builtin_amdg
 //
 // Statistics format: slot t of row m = (s, q) = (sum, sum of squared deviations from the slot's own mean) over columns
 // [t w, (t + 1) w) of the f32 row: within a slot two passes in registers, across slots Chan's pairwise update — no E[x^2] - mean^2
-// cancellation anywhere.  All merges run in a fixed order (deterministic, independent of tile shape: a slot is always reduced
-// from the f32 values of its own columns in the same lane order; the slot WIDTH depends on the producing kernel, see fold_slotw).
+// cancellation anywhere.  All merges run in a fixed order (deterministic, and independent of tile shapes: the unit every kernel
+// reduces is the 32 columns of two accumulator strips in the same lane order; a 64-column slot is the Chan merge of its two halves,
+// which is also what the consumer does with a pair of 32-column slots).
+//
+// Where the work sits (r03a measured the first version — statistics reduced in the consumer's EPILOGUE by the 4 lanes that share a
+// row, with ds_bpermute exchanges and IEEE divisions — at +15-21 us per GEMM launch, more than the LayerNorm launch it replaced):
+//   * consumer: in the kernel PROLOGUE thread t < BM reduces row m0 + t to (mean, rstd) in two registers (ln_row_final: coalesced
+//     8-byte loads, all of a row's slots in flight, v_rcp instead of divisions) while the first K-tiles are in flight; after the K loop
+//     the values are exchanged through the then idle LDS (ln_rows_exchange) — nothing is added to the epilogue's memory round trip;
+//   * producer: the 4-lane reductions use v_permlane16_swap / v_permlane32_swap (VALU, gfx950) instead of ds_bpermute — the LDS pipe
+//     belongs to the co-resident workgroup's K loop — and xg is staged through LDS so that every global store writes full 128-byte lines.
 // ---------------------------------------------------------------------------------------------
 template <int TM> struct LnRows { float mu[TM], rstd[TM]; };
-
-struct LnAgg { float n, mean, m2; };
-__device__ __forceinline__ void ln_merge(LnAgg & a, float nb, float meanb, float m2b) {
-    const float n = a.n + nb;
-    const float d = meanb - a.mean;
-    const float inv = 1.0f / (n > 0.f ? n : 1.f);
-    a.mean += d * (nb * inv);
-    a.m2 += m2b + d * d * (a.n * nb * inv);
-    a.n = n;
+template <int TM> __device__ __forceinline__ void ln_rows_clear(LnRows<TM> & L) {
+#pragma unroll
+    for (int b = 0; b < TM; b++) { L.mu[b] = 0.f; L.rstd[b] = 1.f; }
 }
 
-// (mean, rstd) of the rows this lane's accumulators belong to (row mbase + b * 16 + frow, b < TM).  The 4 lanes that share a row
-// (fgrp = 0..3) each reduce units fgrp, fgrp + 4, ... of the row — a unit is one slot, or with 32-column slots the PAIR (2t, 2t + 1)
-// merged first, which reproduces the 64-column slot of the wider kernels bit for bit, so (mean, rstd) do not depend on the kernel that
-// produced the statistics — TM x ceil(units / 4) x (1 or 2) loads per lane, JC units per row in flight at a time, and combine with
-// two xor-shuffle rounds in lane order.
-template <int TM, int JC = (TM <= 4 ? 8 : 4)>     // JC x TM (x 2) float2 registers in flight
-__device__ __forceinline__ void ln_rows_load(LnRows<TM> & L, const GemmParams & p, int mbase, int frow, int fgrp) {
+// Chan merge of the two 32-column halves of a 64-column slot: (mean, sum of squared deviations) of the 64 columns.  Shared by the
+// producer (64-column kernels) and the consumer (32-column slots arrive in pairs), so both see the same bits.
+__device__ __forceinline__ void ln_pair32(float s0, float q0, float s1, float q1, float & mean, float & m2) {
+    const float m0 = s0 * (1.0f / 32.0f), m1 = s1 * (1.0f / 32.0f);
+    const float d = m1 - m0;
+    mean = m0 + d * 0.5f;
+    m2 = q0 + (q1 + (d * d) * 16.0f);
+}
+
+// value + value of lane ^ 16, then + lane ^ 32: the sum over the 4 lanes (fgrp = 0..3) that hold one accumulator row.  gfx950 VALU
+// swaps: v_permlane16_swap exchanges the odd 16-lane rows of the first operand with the even rows of the second, v_permlane32_swap
+// the upper half-wave of the first with the lower half-wave of the second; with both operands = s the two results add up to the
+// xor-16 / xor-32 butterfly in every lane (inline asm: the builtin form miscompiled the second result in ROCm 7.2).
+__device__ __forceinline__ float sum4_fgrp(float s) {
+    float a = s, b = s;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    s = a + b;
+    a = s; b = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Consumer prologue: (mean, rstd) of row m from its partial statistics, sequential over the units of 64 columns (a pair of 32-column
+// slots merged first, or one slot of any width) in a fixed order.  Called by thread t < BM for row m0 + t: a wave's loads are
+// coalesced.  Straight-line code: chunks of 16 units with every load of a chunk in flight, merge coefficients 1 / (t + 1) and
+// t / (t + 1) folded at compile time, units past the end masked by zero coefficients (r03b: the first version, with a scalar branch
+// per unit and a v_rcp per merge, cost the q/k/v and FFN-up GEMMs 7-9 us per launch).
+template <int C0>
+__device__ __forceinline__ void ln_row_chunk(const float2 * st, size_t stride, int units, bool pairs, float w, float invw, float & mean, float & m2) {
+    constexpr int CH = 16;
+    float mu[CH], q[CH];
+    if (pairs) {
+        float2 v0[CH], v1[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int u = C0 + j < units ? C0 + j : units - 1;
+            v0[j] = st[(size_t)(2 * u) * stride];
+            v1[j] = st[(size_t)(2 * u + 1) * stride];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) ln_pair32(v0[j].x, v0[j].y, v1[j].x, v1[j].y, mu[j], q[j]);
+    } else {
+        float2 v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int u = C0 + j < units ? C0 + j : units - 1;
+            v[j] = st[(size_t)u * stride];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) { mu[j] = v[j].x * invw; q[j] = v[j].y; }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+        constexpr float one = 1.0f;
+        const int t = C0 + j;
+        const float ok = t < units ? one : 0.0f;                      // (wave-uniform: a scalar select)
+        const float k1 = ok * (one / (float)(t + 1));
+        const float k2 = ok * (w * ((float)t / (float)(t + 1)));
+        const float d = mu[j] - mean;
+        mean = mean + d * k1;
+        m2 = m2 + ok * q[j] + (d * d) * k2;
+    }
+}
+
+__device__ __forceinline__ float2 ln_row_final(const GemmParams & p, int m) {
     const bool pairs = p.ln_slotw == 32;
     const int units = pairs ? p.ln_slots >> 1 : p.ln_slots;
     const float w = pairs ? 64.f : (float)p.ln_slotw, invw = 1.0f / w;
-    LnAgg ag[TM];
-    int mrow[TM];
-#pragma unroll
-    for (int b = 0; b < TM; b++) {
-        ag[b].n = 0.f; ag[b].mean = 0.f; ag[b].m2 = 0.f;
-        const int m = mbase + b * 16 + frow;
-        mrow[b] = m < p.M ? m : p.M - 1;
-    }
-    for (int j0 = 0; j0 < units; j0 += 4 * JC) {
-        if (pairs) {
-            float2 v0[TM][JC], v1[TM][JC];
-#pragma unroll
-            for (int j = 0; j < JC; j++) {
-                const int u = j0 + 4 * j + fgrp;
-                const int uc = u < units ? u : units - 1;
-#pragma unroll
-                for (int b = 0; b < TM; b++) {
-                    v0[b][j] = p.ln_stats[(size_t)(2 * uc) * p.ln_stride + mrow[b]];
-                    v1[b][j] = p.ln_stats[(size_t)(2 * uc + 1) * p.ln_stride + mrow[b]];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < JC; j++) {
-                const bool ok = j0 + 4 * j + fgrp < units;
-#pragma unroll
-                for (int b = 0; b < TM; b++) {
-                    LnAgg pr;
-                    pr.n = 32.f; pr.mean = v0[b][j].x * (1.0f / 32.0f); pr.m2 = v0[b][j].y;
-                    ln_merge(pr, 32.f, v1[b][j].x * (1.0f / 32.0f), v1[b][j].y);
-                    if (ok) ln_merge(ag[b], 64.f, pr.mean, pr.m2);
-                }
-            }
-        } else {
-            float2 v[TM][JC];
-#pragma unroll
-            for (int j = 0; j < JC; j++) {
-                const int u = j0 + 4 * j + fgrp;
-                const int uc = u < units ? u : units - 1;
-#pragma unroll
-                for (int b = 0; b < TM; b++) v[b][j] = p.ln_stats[(size_t)uc * p.ln_stride + mrow[b]];
-            }
-#pragma unroll
-            for (int j = 0; j < JC; j++) {
-                const bool ok = j0 + 4 * j + fgrp < units;
-#pragma unroll
-                for (int b = 0; b < TM; b++)
-                    if (ok) ln_merge(ag[b], w, v[b][j].x * invw, v[b][j].y);
-            }
-        }
-    }
+    const float2 * st = p.ln_stats + m;
+    const size_t stride = (size_t)p.ln_stride;
+    float mean = 0.f, m2 = 0.f;
+    ln_row_chunk<0>(st, stride, units, pairs, w, invw, mean, m2);
+    if (units > 16) ln_row_chunk<16>(st, stride, units, pairs, w, invw, mean, m2);      // hidden sizes up to 2048 = 32 units
     const float invh = 1.0f / ((float)p.ln_slots * (float)p.ln_slotw);
+    return make_float2(mean, 1.0f / sqrtf(m2 * invh + p.ln_eps));
+}
+
+// Consumer, after the K loop: thread t < BM parks its row's (mean, rstd) in LDS (the tile buffers are idle: the caller's barrier
+// `sync` separates the last fragment reads from these writes), every lane picks up the TM rows of its accumulators.
+// rs: LDS area of BM float2 that does not overlap the fp16 staging areas of the epilogue.
+template <int TM, typename SYNC>
+__device__ __forceinline__ void ln_rows_exchange(LnRows<TM> & L, float2 * rs, float2 mine, int tid, int BM, int row0, int frow, SYNC sync) {
+    sync();
+    if (tid < BM) rs[tid] = mine;
+    sync();
 #pragma unroll
     for (int b = 0; b < TM; b++) {
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float nb = __shfl_xor(ag[b].n, o), mb_ = __shfl_xor(ag[b].mean, o), qb = __shfl_xor(ag[b].m2, o);
-            // (both partners must end with the same bits: merge in lane order, the lower lane's aggregate first)
-            LnAgg lo, hi;
-            const bool upper = (fgrp * 16) & o;
-            lo.n = upper ? nb : ag[b].n; lo.mean = upper ? mb_ : ag[b].mean; lo.m2 = upper ? qb : ag[b].m2;
-            hi.n = upper ? ag[b].n : nb; hi.mean = upper ? ag[b].mean : mb_; hi.m2 = upper ? ag[b].m2 : qb;
-            ln_merge(lo, hi.n, hi.mean, hi.m2);
-            ag[b] = lo;
-        }
-        L.mu[b] = ag[b].mean;
-        L.rstd[b] = 1.0f / sqrtf(ag[b].m2 * invh + p.ln_eps);
+        const float2 v = rs[row0 + b * 16 + frow];
+        L.mu[b] = v.x;
+        L.rstd[b] = v.y;
     }
 }
 
 // Residual epilogue, producer half of the fold.  acc holds the NEW residual rows (resid + acc + bias, already stored as f32).
 // Writes the partial statistics of the wave's sub-tile — one slot per SW = 64 columns (32 when the wave spans only 32: the ring kernel
 // and the BN = 64 tiles; gemm_fold_slotw() tells the consumer which) — and xg = fp16(x gamma_next), the next GEMM's A operand.
+// stage: this wave's private LDS staging area ((TM * 16) rows x 68 halfs, idle tile buffers) or nullptr.  Staged, every global store
+// instruction writes 8 full 128-byte lines; unstaged (ring kernel, 64-row tiles) a store covers 16 rows x 32 bytes.
 template <int TN> constexpr int fold_slotw() { return TN * 16 >= 64 ? 64 : 32; }
 
 template <int TN, int TM>
-__device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp) {
+__device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
+                                                half_t * stage, int lane) {
     constexpr int SW = fold_slotw<TN>(), SA = SW / 16;         // strips (16 columns each) per slot
     static_assert(TN % SA == 0, "a wave's columns are whole statistics slots");
     const int N = p.W.N;
@@ -256,7 +276,7 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
 #pragma unroll
     for (int sp = 0; sp < TN / SA; sp++) {
         const int n = nbase + sp * SW;
-        if (n >= N) continue;                                  // (uniform; N is a multiple of 64 on this path: launch_gemm checks)
+        if (n >= N) continue;                                  // (uniform; N is a multiple of 64 on this path: the loader checks)
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             // canonical unit: 32 columns = 2 strips x 4 columns in this lane x the 4 lanes (fgrp) that share the row, two passes
@@ -264,28 +284,52 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
 #pragma unroll
             for (int i = 0; i < SA / 2; i++) {
                 const f4 u = acc[sp * SA + 2 * i][b], v = acc[sp * SA + 2 * i + 1][b];
-                float s = ((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3]));
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
+                const float s = sum4_fgrp(((u[0] + u[1]) + (u[2] + u[3])) + ((v[0] + v[1]) + (v[2] + v[3])));
                 const float mean = s * (1.0f / 32.0f);
                 const f4 du = u - mean, dv = v - mean;
-                float q = ((du[0] * du[0] + du[1] * du[1]) + (du[2] * du[2] + du[3] * du[3])) +
-                          ((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]));
-                q += __shfl_xor(q, 16);
-                q += __shfl_xor(q, 32);
+                const float q = sum4_fgrp(((du[0] * du[0] + du[1] * du[1]) + (du[2] * du[2] + du[3] * du[3])) +
+                                          ((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])));
                 s32[i] = s; q32[i] = q;
             }
             float2 o;
             if constexpr (SW == 64) {       // the 64-column slot = Chan merge of its two halves (what the consumer does with 32-column slots)
-                LnAgg pr;
-                pr.n = 32.f; pr.mean = s32[0] * (1.0f / 32.0f); pr.m2 = q32[0];
-                ln_merge(pr, 32.f, s32[1] * (1.0f / 32.0f), q32[1]);
-                o = make_float2(pr.mean * 64.f, pr.m2);
+                float mean64, q64;
+                ln_pair32(s32[0], q32[0], s32[1], q32[1], mean64, q64);
+                o = make_float2(mean64 * 64.f, q64);
             } else {
                 o = make_float2(s32[0], q32[0]);
             }
             const int m = mbase + b * 16 + frow;
             if (fgrp == 0 && m < p.M) p.stats_out[(size_t)(n / SW) * p.stats_stride + m] = o;
+        }
+    }
+    if constexpr (TN % 4 == 0) {
+        if (stage != nullptr && (p.ldxg & 7) == 0) {
+            // 64 columns at a time through the wave's staging rows (136-byte pitch: conflict-free 8-byte writes), re-read row-contiguous
+            constexpr int RS = 68;
+            const int rrow = lane >> 3, rchunk = lane & 7;
+#pragma unroll
+            for (int hb = 0; hb < TN / 4; hb++) {
+                const int n0 = nbase + hb * 64;
+                if (n0 >= N) continue;
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < TM; b++) {
+                        const f4 g = acc[hb * 4 + a][b] * gam[hb * 4 + a];
+                        const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]};
+                        const h2 hi = (h2){(_Float16)g[2], (_Float16)g[3]};
+                        *(uint2 *)(stage + (b * 16 + frow) * RS + a * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
+                    }
+#pragma unroll
+                for (int i = 0; i < TM * 2; i++) {
+                    const int ml = i * 8 + rrow;
+                    const int m = mbase + ml;
+                    const u32x4 v = *(const u32x4 *)(stage + ml * RS + rchunk * 8);
+                    if (m < p.M) *(u32x4 *)(p.xg_out + (size_t)m * p.ldxg + n0 + rchunk * 8) = v;
+                }
+            }
+            return;
         }
     }
 #pragma unroll
@@ -315,10 +359,10 @@ __device__ __forceinline__ f4 ln_apply(bool ln, const LnRows<TM> & L, int b, con
 // nbase / mbase: first weight row / activation row of this wave's sub-tile.
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
-                                              const LnRows<TM> * ln_pre = nullptr) {
+                                              bool ln_on, const LnRows<TM> & L, half_t * stage = nullptr, int lane = 0) {
     const int N = p.W.N;
     constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;   // epilogues that can consume a folded LayerNorm
-    const bool ln = LNE && p.ln_c != nullptr;
+    const bool ln = LNE && ln_on;      // L = (mean, rstd) of this lane's rows: ln_row_final + ln_rows_exchange in the kernel
     // Everything the K loop requested has landed.  Said with the BUILTIN so that hipcc's waitcnt pass sees it: an LDS-DMA request
     // (a FLAT-encoded instruction touching two address spaces) leaves that pass in its "pending flat" state, in which every later
     // wait is vmcnt(0) / lgkmcnt(0) — in an epilogue that means each group of loads also waits for all earlier STORES to be acked.
@@ -332,7 +376,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
         biasv[a] = (EPI != EPI_PATCH_F32 && p.bias) ? *(const f4 *)(p.bias + n) : (f4){0.f, 0.f, 0.f, 0.f};
     }
     f4 cv[LNE ? TN : 1];
-    LnRows<TM> L;
     if constexpr (LNE) {
         if (ln) {          // same batch of loads as the bias vectors: one memory round trip
 #pragma unroll
@@ -341,8 +384,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
                 n = n < N ? n : 0;
                 cv[a] = *(const f4 *)(p.ln_c + n);
             }
-            if (ln_pre) L = *ln_pre;
-            else ln_rows_load<TM>(L, p, mbase, frow, fgrp);
         }
     }
     if constexpr (EPI == EPI_RESID_F32) {
@@ -374,7 +415,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
                 if (m < p.M) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = acc[a][b];
             }
         }
-        if (p.xg_out) resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp);
+        if (p.xg_out) resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp, stage, lane);
         return;
     }
 #pragma unroll
@@ -436,7 +477,7 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
                     if (n < N && m < p.M) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = acc[a][b];
                 }
             }
-            resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp);
+            resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp, nullptr, 0);
             return;
         }
     }
@@ -485,20 +526,16 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
 // Requires BN/2 == 64, the whole n range of the wave inside N, and a 16-byte aligned output row (ldc % 8 == 0).
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
-                                                         half_t * stage, int lane, const LnRows<TM> * ln_pre = nullptr) {
+                                                         half_t * stage, int lane, bool ln, const LnRows<TM> & L) {
     constexpr int RS = 68;                                     // halfs per staged row (64 + 4 pad = 136 B)
     __builtin_amdgcn_s_waitcnt(0x0070);                        // (see gemm_epilogue: lets hipcc count its waits again)
     f4 biasv[TN];                                              // one batch of loads, not TN dependent round trips
 #pragma unroll
     for (int a = 0; a < TN; a++) biasv[a] = p.bias ? *(const f4 *)(p.bias + nbase + a * 16 + fgrp * 4) : (f4){0.f, 0.f, 0.f, 0.f};
-    const bool ln = p.ln_c != nullptr;                         // LayerNorm folded into this GEMM (see ln_rows_load)
-    f4 cv[TN];
-    LnRows<TM> L;
+    f4 cv[TN];                                                 // ln: LayerNorm folded into this GEMM, L = (mean, rstd) of this lane's rows
     if (ln) {
 #pragma unroll
         for (int a = 0; a < TN; a++) cv[a] = *(const f4 *)(p.ln_c + nbase + a * 16 + fgrp * 4);
-        if (ln_pre) L = *ln_pre;
-        else ln_rows_load<TM>(L, p, mbase, frow, fgrp);
     }
 #pragma unroll
     for (int a = 0; a < TN; a++) {

@@ -234,6 +234,14 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
     DMA_TILE(0, 0);
     LOAD_B(B0, 0);
     { const int t1 = last < 1 ? last : 1; LOAD_B(B1, t1); }
+    // LayerNorm folded into this GEMM (gemm_common.h): thread t < BM reduces the statistics of row m0 + t to (mean, rstd) while the
+    // first tiles are in flight; the epilogue picks them up through LDS
+    constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
+    const bool ln = LNE && p.ln_c != nullptr;
+    float2 ln_mine = make_float2(0.f, 1.f);
+    if constexpr (LNE) {
+        if (ln && tid < BM) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
+    }
     STORE_B(B0, 0);
     __syncthreads();
     int kt = 0;
@@ -330,15 +338,28 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
             }
         }
     }
+    // LDS after the K loop: [0, BM * 272) the four waves' fp16 staging areas ((BM / 2) rows x 136 bytes each), then BM float2 of row statistics
+    LnRows<TM> lnr;
+    ln_rows_clear<TM>(lnr);
+    if constexpr (LNE) {
+        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)(smem_raw + ((BM * 272 + 15) & ~15)), ln_mine, tid, BM, wm * (BM / 2), frow, [] { __syncthreads(); });
+    }
     if constexpr ((EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) && BN == 128 && BM >= 128) {
         const int nb = n0 + wn * (BN / 2);
         if (nb + BN / 2 <= p.W.N && (p.ldc & 7) == 0) {                 // uniform per wave
-            if (nk & 1) __syncthreads();                                 // odd K-step count: the tail COMPUTE(0) had no barrier behind it
-            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, m0 + wm * (BM / 2), frow, fgrp, (half_t *)smem_raw + wave * (BM / 2) * 68, lane);
+            if ((nk & 1) && !ln) __syncthreads();                        // odd K-step count: the tail COMPUTE(0) had no barrier behind it
+            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, m0 + wm * (BM / 2), frow, fgrp, (half_t *)smem_raw + wave * (BM / 2) * 68, lane, ln, lnr);
             return;
         }
     }
-    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp);
+    if constexpr (EPI == EPI_RESID_F32 && BN == 128 && BM >= 128) {
+        if (p.xg_out) {       // producer half of the fold: xg goes through the wave's staging area (full-line stores)
+            if (nk & 1) __syncthreads();
+            gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp, false, lnr, (half_t *)smem_raw + wave * (BM / 2) * 68, lane);
+            return;
+        }
+    }
+    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp, ln, lnr);
 }
 
 template <int WT, int BM, int BN, int EPI>

@@ -229,6 +229,15 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
     const bool stamper = p.sk_ws && tid == 0;
     if (stamper) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+    // LayerNorm folded into this GEMM (gemm_common.h): thread t < BM reduces the statistics of row m0 + t to (mean, rstd) before the
+    // first request (the counted waits below then see only tile requests); the epilogue picks the values up through LDS
+    constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
+    const bool ln = LNE && p.ln_c != nullptr;
+    float2 ln_mine = make_float2(0.f, 1.f);
+    if constexpr (LNE) {
+        if (ln && tid < BM) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
+        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): said with the builtin so that hipcc's own counting restarts from zero
+    }
     ISSUE_W(0, 0);
     ISSUE_X(0, 0);
     if (S == 3 && T > 1) {
@@ -261,14 +270,21 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();
 #endif
+    // LDS after the K loop: 8 fp16 staging areas of (TM * 16) rows x 136 bytes, then BM float2 of row statistics
+    LnRows<TM> lnr;
+    ln_rows_clear<TM>(lnr);
+    if constexpr (LNE) {
+        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)(smem + 8 * (TM * 16) * 136), ln_mine, tid, BM, wm * TM * 16, frow, [] { __syncthreads(); });
+    }
+    half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
     bool done = false;
     if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
         if (nb + 64 <= p.W.N && (p.ldc & 7) == 0) {    // uniform per wave
-            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, (half_t *)smem + wave * (TM * 16) * 68, lane);
+            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, stage, lane, ln, lnr);
             done = true;
         }
     }
-    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp);
+    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, lnr, stage, lane);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();       // stores issued (not necessarily landed)
@@ -284,7 +300,8 @@ void launch8(const GemmParams & p, hipStream_t stream) {
     constexpr int BM = 32 * TM;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.W.N + 255) / 256;
     constexpr size_t ring = (size_t)(3 * (BM + 256) * 128 <= 160 * 1024 ? 3 : 2) * (BM + 256) * 128;
-    constexpr size_t stage_out = (size_t)8 * (TM * 16) * 68 * sizeof(half_t);      // fp16 epilogues stage the tile through LDS
+    // fp16 epilogues stage the tile through LDS; behind the 8 staging areas sit the BM float2 of row statistics of the LayerNorm fold
+    constexpr size_t stage_out = (size_t)8 * (TM * 16) * 68 * sizeof(half_t) + (size_t)BM * sizeof(float2);
     constexpr size_t smem = ring > stage_out ? ring : stage_out;
     static_assert(smem <= 160 * 1024, "tile does not fit the LDS");
     static unsigned long long lds_ok = 0;

@@ -327,16 +327,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
 #endif
 #pragma unroll
     for (int s = 0; s < NS - 1; s++) RING_ISSUE(s, (s < last ? s : last));
-    // LayerNorm folded into this GEMM (gemm_common.h): the row statistics and the c vector are fetched behind the prologue requests
-    // and waited for before the loop (their wait also lands the prologue tiles), so the counted waits of the loop see only its own requests
+    // LayerNorm folded into this GEMM (gemm_common.h): thread t < 64 reduces the statistics of row m0 + t to (mean, rstd), and the c
+    // vector is fetched, behind the prologue requests; hipcc's wait for these loads (before the loop) also lands the prologue tiles,
+    // so the counted waits of the loop see only the loop's own requests
     constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
-    const bool ln = LNE && p.ln_c != nullptr && ksplit == 1;
+    const bool ln = LNE && p.ln_c != nullptr;
     f4 c_pre[TN];
-    LnRows<TM> lnr;
+    float2 ln_mine = make_float2(0.f, 1.f);
 #pragma unroll
     for (int a = 0; a < TN; a++) c_pre[a] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < TM; b++) { lnr.mu[b] = 0.f; lnr.rstd[b] = 1.f; }
     if constexpr (LNE) {
         if (ln) {
 #pragma unroll
@@ -345,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
                 n = n < p.W.N ? n : 0;
                 c_pre[a] = *(const f4 *)(p.ln_c + n);
             }
-            ln_rows_load<TM>(lnr, p, mb_w, frow, fgrp);
+            if (tid < RBM) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
         }
     }
     int st = 0;                // stage of tile kt
@@ -376,6 +375,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();     // (before the final wait: the "epilogue" span includes it)
 #endif
     ring_wait_vmcnt<0>();      // nothing may land in this LDS allocation after the workgroup has left it
+    LnRows<TM> lnr;
+    ln_rows_clear<TM>(lnr);
+    if constexpr (LNE) {
+        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)smem, ln_mine, tid, RBM, wm * (RBM / WM), frow, [] { __syncthreads(); });
+    }
 #undef RING_ISSUE
 #undef RING_COMPUTE
 #undef RING_RAW
@@ -424,7 +428,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
         }
     }
     if (ksplit == 1) gemm_epilogue_pre<EPI, TN, TM>(p, acc, bias_pre, resid_pre, nb_w, mb_w, frow, fgrp, ln, c_pre, lnr);
-    else gemm_epilogue<EPI, TN, TM>(p, acc, nb_w, mb_w, frow, fgrp);
+    else gemm_epilogue<EPI, TN, TM>(p, acc, nb_w, mb_w, frow, fgrp, ln, lnr);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();

@@ -56,8 +56,10 @@ def test_two_tower_parity_small_models(gpu, fixture_cache, config, ftype):
         assert one_minus_cos(single, want) <= TOL[ftype], (config, ftype, i)
         # ragged batch == one-at-a-time, up to the fp32 re-association between the batch's tiled GEMMs and the single text's
         # small-M kernels (k_skinny.hip: intra-workgroup split-K, LayerNorm statistics from partial sums)
+        # ... and, since round 3, the rounding placement of the LayerNorm fold (batches of > 64 rows multiply fp16(x gamma) and finish
+        # the normalisation in the GEMM epilogue; the small-M kernels round the normalised value): a few 1e-4 on these 32-64-wide towers
         assert one_minus_cos(batch[i], single) <= 1e-6, (config, ftype, i)
-        np.testing.assert_allclose(batch[i], single, atol=3e-4)
+        np.testing.assert_allclose(batch[i], single, atol=1e-3)
     clip.close()
 
 
@@ -224,8 +226,9 @@ def test_layernorm_fold_matches_the_layernorm_kernel_form_end_to_end(gpu, fixtur
     monkeypatch.delenv("CLIP_AMD_LNFOLD")
     assert np.all(one_minus_cos(got_i, ref_i) <= 1e-6), one_minus_cos(got_i, ref_i).max()
     assert np.all(one_minus_cos(got_t, ref_t) <= 1e-6), one_minus_cos(got_t, ref_t).max()
-    np.testing.assert_allclose(got_i, ref_i, atol=3e-4)
-    np.testing.assert_allclose(got_t, ref_t, atol=3e-4)
+    atol = 3e-4 if config == "b32" else 1e-3          # (the 64-128-wide test towers: one fp16 rounding flip is a larger share of an element)
+    np.testing.assert_allclose(got_i, ref_i, atol=atol)
+    np.testing.assert_allclose(got_t, ref_t, atol=atol)
 
 
 @pytest.mark.parametrize("ftype", ["f16", "q4_0"])
@@ -284,15 +287,21 @@ def test_vit_l14_batch130_largest_m_kernels_match_single_images(gpu, fixture_cac
 
 def test_batches_beyond_one_workspace_chunk_and_stream_restore(gpu, fixture_cache):
     """More images than one forward chunk (1024) and than one host-API staging chunk (256): rows must equal the small-batch
-    results bit for bit (tiny model: no split-K at any size); clip_amd_set_stream(NULL) restores the context's own stream."""
+    results bit for bit (tiny model: no split-K at any size; batches of > 64 token rows: the LayerNorm statistics do not depend on
+    the tile shapes either); clip_amd_set_stream(NULL) restores the context's own stream."""
     torch = pytest.importorskip("torch")
     p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=False, vision=True)
     clip = gpu.Clip(p, device=0)
     imgs = fixtures.synthetic_images(1030, 32, seed=77)
     full = clip.encode_images(imgs)                                   # host API: 5 staging chunks
     assert full.shape == (1030, 32) and np.all(np.isfinite(full))
-    for i in (0, 255, 256, 1023, 1024, 1029):
-        assert np.array_equal(clip.encode_images(imgs[i:i + 1])[0], full[i]), i
+    for i in (0, 255, 256, 1023, 1024, 1026):
+        # 4 images = 68 token rows: other tiles, other kernels (ring instead of the large tiles), the same LayerNorm-folded chain
+        assert np.array_equal(clip.encode_images(imgs[i:i + 4])[0], full[i]), i
+        # one image = 17 rows: the small-M kernels (LayerNorm fused on the operand instead of folded into the epilogue)
+        one = clip.encode_images(imgs[i:i + 1])
+        assert one_minus_cos(one, full[i:i + 1])[0] <= 1e-6, i
+        np.testing.assert_allclose(one[0], full[i], atol=1e-3)
     d_in = torch.from_numpy(imgs).cuda()
     d_out = torch.empty((1030, 32), dtype=torch.float32, device="cuda")
     st = torch.cuda.Stream()
@@ -302,7 +311,7 @@ def test_batches_beyond_one_workspace_chunk_and_stream_restore(gpu, fixture_cach
         st.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), full)
     clip.set_stream(0)                                                 # NULL -> own stream again
-    assert np.array_equal(clip.encode_images(imgs[:3]), full[:3])
+    assert np.array_equal(clip.encode_images(imgs[:5]), full[:5])
 
 
 def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
@@ -371,7 +380,7 @@ def test_batched_zero_shot_on_gpu_matches_per_image_reference_composition(gpu, f
     for i, im in enumerate(images):
         u8 = gpu.ClipImageU8(im.shape[1], im.shape[0], im.ctypes.data_as(C.POINTER(C.c_uint8)), im.size)
         s1, i1 = clip.zero_shot_label_pixels(C.byref(u8), labels)
-        np.testing.assert_allclose(scores[i], s1, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(scores[i], s1, rtol=1e-4, atol=1e-6)     # (labels as ONE folded batch vs one label at a time on the small-M kernels)
         assert list(idx[i]) == i1, (i, list(idx[i]), i1)
         assert abs(scores[i].sum() - 1.0) < 1e-5 and np.all(np.diff(scores[i]) <= 0)
         assert sorted(idx[i]) == list(range(len(labels)))

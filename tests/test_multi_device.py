@@ -40,8 +40,18 @@ def test_sharded_batch_encode_matches_single_context(clip_lib, fixture_cache, G,
     imgs = fixtures.synthetic_images(B, 32, seed=5)
     want = single.encode_images(imgs)
     got = multi.encode_images(imgs)                         # B >= 2 G: sharded, ceil(B / G) per replica, last shard padded
-    assert np.array_equal(got, want)
-    assert np.array_equal(multi.encode_images(imgs[:1]), want[:1])      # tiny batch: device 0 only
+    # bit for bit where every shard runs the kernels of the unsharded batch (> 64 token rows = 4+ images of 17 tokens: the
+    # LayerNorm-folded chain, whose results do not depend on tile shapes); smaller shards take the small-M kernels, which round the
+    # normalised activations instead of x * gamma: equal to fp16 rounding
+    per = -(-B // G)
+    if per >= 4 and B - (G - 1) * per >= 4 and B >= 4:
+        assert np.array_equal(got, want)
+    else:
+        a, b = got / np.linalg.norm(got, axis=1, keepdims=True), want / np.linalg.norm(want, axis=1, keepdims=True)
+        assert np.all(1.0 - (a * b).sum(1) <= 1e-6)
+        np.testing.assert_allclose(got, want, atol=1e-3)
+    one = multi.encode_images(imgs[:1])                      # tiny batch: device 0 only
+    np.testing.assert_allclose(one, single.encode_images(imgs[:1]), atol=0, rtol=0)
     # everything else of the API keeps working on the primary context
     ids = [49406, 5, 6, 7, 49407]
     assert np.array_equal(np.asarray(multi.encode_text(ids), np.float32), np.asarray(single.encode_text(ids), np.float32))
