@@ -723,7 +723,23 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
         p.w16_scratch = (half_t *)panel.p; p.w16_scratch_halfs = panel.p ? (size_t)W.Npad * W.Kpad : 0;
     }
     p.debug = (epilogue >> 8) & 0xFF;   // ablation switches (tuning only)
+    // bit 17: time the epilogue with the LayerNorm fold — consumer form for the fp16 epilogues (row statistics + c vector), producer form
+    // (xg + statistics out) for the residual epilogue
+    const bool fold = (epilogue >> 17) & 1;
     epilogue &= 0xFF;
+    const int st_stride = (int)((M + 63) & ~(int64_t)63);
+    DBuf dstats(fold ? (size_t)(N > K ? N : K) / 32 * st_stride * 8 + 64 : 16), dvec(fold ? (size_t)(N > K ? N : K) * 4 + 64 : 16), dxg(fold ? (size_t)M * N * 2 + 64 : 16);
+    if (fold) {
+        std::vector<float> hs((size_t)(N > K ? N : K) / 32 * st_stride * 2), hv((size_t)(N > K ? N : K), 1.0f);
+        for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 0.5f * 64; hs[i + 1] = 60.f; }
+        (void)hipMemcpy(dstats.p, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dvec.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice);
+        if (epilogue == EPI_RESID_F32) {
+            p.xg_out = (half_t *)dxg.p; p.ldxg = (int)N; p.xg_gamma = (const float *)dvec.p; p.stats_out = (float2 *)dstats.p; p.stats_stride = st_stride;
+        } else if (epilogue == EPI_F16 || epilogue == EPI_GELU_F16 || epilogue == EPI_QGELU_F16) {
+            p.ln_c = (const float *)dvec.p; p.ln_stats = (const float2 *)dstats.p; p.ln_slotw = 64; p.ln_slots = (int)K / 64; p.ln_stride = st_stride; p.ln_eps = 1e-5f;
+        }
+    }
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);

@@ -154,12 +154,6 @@ __device__ __forceinline__ float gelu_quick(float x) { return x * __builtin_amdg
 //   * producer: the 4-lane reductions use v_permlane16_swap / v_permlane32_swap (VALU, gfx950) instead of ds_bpermute — the LDS pipe
 //     belongs to the co-resident workgroup's K loop — and xg is staged through LDS so that every global store writes full 128-byte lines.
 // ---------------------------------------------------------------------------------------------
-template <int TM> struct LnRows { float mu[TM], rstd[TM]; };
-template <int TM> __device__ __forceinline__ void ln_rows_clear(LnRows<TM> & L) {
-#pragma unroll
-    for (int b = 0; b < TM; b++) { L.mu[b] = 0.f; L.rstd[b] = 1.f; }
-}
-
 // Chan merge of the two 32-column halves of a 64-column slot: (mean, sum of squared deviations) of the 64 columns.  Shared by the
 // producer (64-column kernels) and the consumer (32-column slots arrive in pairs), so both see the same bits.
 __device__ __forceinline__ void ln_pair32(float s0, float q0, float s1, float q1, float & mean, float & m2) {
@@ -238,19 +232,19 @@ __device__ __forceinline__ float2 ln_row_final(const GemmParams & p, int m) {
 }
 
 // Consumer, after the K loop: thread t < BM parks its row's (mean, rstd) in LDS (the tile buffers are idle: the caller's barrier
-// `sync` separates the last fragment reads from these writes), every lane picks up the TM rows of its accumulators.
-// rs: LDS area of BM float2 that does not overlap the fp16 staging areas of the epilogue.
-template <int TM, typename SYNC>
-__device__ __forceinline__ void ln_rows_exchange(LnRows<TM> & L, float2 * rs, float2 mine, int tid, int BM, int row0, int frow, SYNC sync) {
+// `sync` separates the last fragment reads from these writes); the epilogues read the TM rows of a lane's accumulators from there
+// (ln_rows_read).  rs: LDS area of BM float2 that does not overlap the fp16 staging areas of the epilogue.
+template <typename SYNC>
+__device__ __forceinline__ void ln_rows_publish(float2 * rs, float2 mine, int tid, int BM, SYNC sync) {
     sync();
     if (tid < BM) rs[tid] = mine;
     sync();
+}
+// rs_lane = rs + (first row of the wave's sub-tile) + frow
+template <int TM>
+__device__ __forceinline__ void ln_rows_read(float2 (&mr)[TM], bool ln, const float2 * rs_lane) {
 #pragma unroll
-    for (int b = 0; b < TM; b++) {
-        const float2 v = rs[row0 + b * 16 + frow];
-        L.mu[b] = v.x;
-        L.rstd[b] = v.y;
-    }
+    for (int b = 0; b < TM; b++) mr[b] = ln ? rs_lane[b * 16] : make_float2(0.f, 1.f);
 }
 
 // Residual epilogue, producer half of the fold.  acc holds the NEW residual rows (resid + acc + bias, already stored as f32).
@@ -266,17 +260,16 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
     constexpr int SW = fold_slotw<TN>(), SA = SW / 16;         // strips (16 columns each) per slot
     static_assert(TN % SA == 0, "a wave's columns are whole statistics slots");
     const int N = p.W.N;
-    f4 gam[TN];
-#pragma unroll
-    for (int a = 0; a < TN; a++) {
-        int n = nbase + a * 16 + fgrp * 4;
-        n = n < N ? n : 0;
-        gam[a] = *(const f4 *)(p.xg_gamma + n);
-    }
+    const bool staged = SA == 4 && stage != nullptr && (p.ldxg & 7) == 0;
+    // one statistics slot (SA strips) at a time: its gamma values, its statistics, its xg columns (a 128 x 128 wave sub-tile of
+    // k_gemm4.hip would otherwise hold 8 strips of gamma beside its accumulators)
 #pragma unroll
     for (int sp = 0; sp < TN / SA; sp++) {
         const int n = nbase + sp * SW;
         if (n >= N) continue;                                  // (uniform; N is a multiple of 64 on this path: the loader checks)
+        f4 gam[SA];
+#pragma unroll
+        for (int i = 0; i < SA; i++) gam[i] = *(const f4 *)(p.xg_gamma + n + i * 16 + fgrp * 4);
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             // canonical unit: 32 columns = 2 strips x 4 columns in this lane x the 4 lanes (fgrp) that share the row, two passes
@@ -302,21 +295,17 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
             const int m = mbase + b * 16 + frow;
             if (fgrp == 0 && m < p.M) p.stats_out[(size_t)(n / SW) * p.stats_stride + m] = o;
         }
-    }
-    if constexpr (TN % 4 == 0) {
-        if (stage != nullptr && (p.ldxg & 7) == 0) {
-            // 64 columns at a time through the wave's staging rows (136-byte pitch: conflict-free 8-byte writes), re-read row-contiguous
-            constexpr int RS = 68;
-            const int rrow = lane >> 3, rchunk = lane & 7;
-#pragma unroll
-            for (int hb = 0; hb < TN / 4; hb++) {
-                const int n0 = nbase + hb * 64;
-                if (n0 >= N) continue;
+        if constexpr (SA == 4) {
+            if (staged) {
+                // 64 columns through the wave's staging rows (136-byte pitch: conflict-free 8-byte writes), re-read row-contiguous:
+                // every global store instruction then writes 8 full 128-byte lines
+                constexpr int RS = 68;
+                const int rrow = lane >> 3, rchunk = lane & 7;
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
                     for (int b = 0; b < TM; b++) {
-                        const f4 g = acc[hb * 4 + a][b] * gam[hb * 4 + a];
+                        const f4 g = acc[sp * 4 + a][b] * gam[a];
                         const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]};
                         const h2 hi = (h2){(_Float16)g[2], (_Float16)g[3]};
                         *(uint2 *)(stage + (b * 16 + frow) * RS + a * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
@@ -326,32 +315,28 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
                     const int ml = i * 8 + rrow;
                     const int m = mbase + ml;
                     const u32x4 v = *(const u32x4 *)(stage + ml * RS + rchunk * 8);
-                    if (m < p.M) *(u32x4 *)(p.xg_out + (size_t)m * p.ldxg + n0 + rchunk * 8) = v;
+                    if (m < p.M) *(u32x4 *)(p.xg_out + (size_t)m * p.ldxg + n + rchunk * 8) = v;
                 }
+                continue;
             }
-            return;
         }
-    }
 #pragma unroll
-    for (int a = 0; a < TN; a++) {
-        const int n = nbase + a * 16 + fgrp * 4;
-        if (n >= N) continue;
+        for (int i = 0; i < SA; i++)
 #pragma unroll
-        for (int b = 0; b < TM; b++) {
-            const int m = mbase + b * 16 + frow;
-            if (m >= p.M) continue;
-            const f4 g = acc[a][b] * gam[a];
-            const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]};
-            const h2 hi = (h2){(_Float16)g[2], (_Float16)g[3]};
-            *(uint2 *)(p.xg_out + (size_t)m * p.ldxg + n) = make_uint2(h2u(lo), h2u(hi));
-        }
+            for (int b = 0; b < TM; b++) {
+                const int m = mbase + b * 16 + frow;
+                if (m >= p.M) continue;
+                const f4 g = acc[sp * SA + i][b] * gam[i];
+                const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]};
+                const h2 hi = (h2){(_Float16)g[2], (_Float16)g[3]};
+                *(uint2 *)(p.xg_out + (size_t)m * p.ldxg + n + i * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
+            }
     }
 }
 
 // consumer half: v = acc + bias, or with the fold rstd_m (acc - mean_m c_n) + b'_n
-template <int TM>
-__device__ __forceinline__ f4 ln_apply(bool ln, const LnRows<TM> & L, int b, const f4 & acc, const f4 & c, const f4 & bias) {
-    if (ln) return (acc - c * L.mu[b]) * L.rstd[b] + bias;
+__device__ __forceinline__ f4 ln_apply(bool ln, const float2 & mr, const f4 & acc, const f4 & c, const f4 & bias) {
+    if (ln) return (acc - c * mr.x) * mr.y + bias;
     return acc + bias;
 }
 
@@ -359,10 +344,10 @@ __device__ __forceinline__ f4 ln_apply(bool ln, const LnRows<TM> & L, int b, con
 // nbase / mbase: first weight row / activation row of this wave's sub-tile.
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
-                                              bool ln_on, const LnRows<TM> & L, half_t * stage = nullptr, int lane = 0) {
+                                              bool ln_on, const float2 * rs_lane, half_t * stage = nullptr, int lane = 0) {
     const int N = p.W.N;
     constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;   // epilogues that can consume a folded LayerNorm
-    const bool ln = LNE && ln_on;      // L = (mean, rstd) of this lane's rows: ln_row_final + ln_rows_exchange in the kernel
+    const bool ln = LNE && ln_on;      // rs_lane: (mean, rstd) of this lane's rows in LDS (ln_row_final + ln_rows_publish in the kernel)
     // Everything the K loop requested has landed.  Said with the BUILTIN so that hipcc's waitcnt pass sees it: an LDS-DMA request
     // (a FLAT-encoded instruction touching two address spaces) leaves that pass in its "pending flat" state, in which every later
     // wait is vmcnt(0) / lgkmcnt(0) — in an epilogue that means each group of loads also waits for all earlier STORES to be acked.
@@ -376,7 +361,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
         biasv[a] = (EPI != EPI_PATCH_F32 && p.bias) ? *(const f4 *)(p.bias + n) : (f4){0.f, 0.f, 0.f, 0.f};
     }
     f4 cv[LNE ? TN : 1];
+    float2 mr[LNE ? TM : 1];
     if constexpr (LNE) {
+        ln_rows_read<TM>(mr, ln, rs_lane);
         if (ln) {          // same batch of loads as the bias vectors: one memory round trip
 #pragma unroll
             for (int a = 0; a < TN; a++) {
@@ -428,7 +415,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
             const int m = mbase + b * 16 + frow;
             if (m >= p.M) continue;
             f4 v;
-            if constexpr (LNE) v = ln_apply<TM>(ln, L, b, acc[a][b], cv[a], bias);
+            if constexpr (LNE) v = ln_apply(ln, mr[b], acc[a][b], cv[a], bias);
             else v = acc[a][b] + bias;
             if constexpr (EPI == EPI_F32) {
                 *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
@@ -462,9 +449,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
 // a memory round trip per strip (measured there: 7 us of a 60 us kernel at 64 x 256 tiles).  Same expressions, same rounding.
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc)[TN][TM], const f4 (&biasv)[TN], const f4 (&rpre)[TN][TM],
-                                                  int nbase, int mbase, int frow, int fgrp, bool ln, const f4 (&cv)[TN], const LnRows<TM> & L) {
+                                                  int nbase, int mbase, int frow, int fgrp, bool ln, const f4 (&cv)[TN], const float2 * rs_lane) {
     const int N = p.W.N;
     constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
+    float2 mr[LNE ? TM : 1];
+    if constexpr (LNE) ln_rows_read<TM>(mr, ln, rs_lane);
     if constexpr (EPI == EPI_RESID_F32) {
         if (p.xg_out) {          // producer half of the LayerNorm fold: every lane keeps its new rows (also past M: never stored)
 #pragma unroll
@@ -491,7 +480,7 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
             const int m = mbase + b * 16 + frow;
             if (m >= p.M) continue;
             f4 v;
-            if constexpr (LNE) v = ln_apply<TM>(ln, L, b, acc[a][b], cv[a], bias);
+            if constexpr (LNE) v = ln_apply(ln, mr[b], acc[a][b], cv[a], bias);
             else v = acc[a][b] + bias;
             if constexpr (EPI == EPI_F32) {
                 *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
@@ -526,13 +515,15 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
 // Requires BN/2 == 64, the whole n range of the wave inside N, and a 16-byte aligned output row (ldc % 8 == 0).
 template <int EPI, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
-                                                         half_t * stage, int lane, bool ln, const LnRows<TM> & L) {
+                                                         half_t * stage, int lane, bool ln, const float2 * rs_lane) {
     constexpr int RS = 68;                                     // halfs per staged row (64 + 4 pad = 136 B)
     __builtin_amdgcn_s_waitcnt(0x0070);                        // (see gemm_epilogue: lets hipcc count its waits again)
     f4 biasv[TN];                                              // one batch of loads, not TN dependent round trips
 #pragma unroll
     for (int a = 0; a < TN; a++) biasv[a] = p.bias ? *(const f4 *)(p.bias + nbase + a * 16 + fgrp * 4) : (f4){0.f, 0.f, 0.f, 0.f};
-    f4 cv[TN];                                                 // ln: LayerNorm folded into this GEMM, L = (mean, rstd) of this lane's rows
+    f4 cv[TN];                                                 // ln: LayerNorm folded into this GEMM, rs_lane = (mean, rstd) of this lane's rows (LDS)
+    float2 mr[TM];
+    ln_rows_read<TM>(mr, ln, rs_lane);
     if (ln) {
 #pragma unroll
         for (int a = 0; a < TN; a++) cv[a] = *(const f4 *)(p.ln_c + nbase + a * 16 + fgrp * 4);
@@ -543,7 +534,7 @@ __device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f
         const f4 bias = biasv[a];
 #pragma unroll
         for (int b = 0; b < TM; b++) {
-            f4 v = ln_apply<TM>(ln, L, b, acc[a][b], cv[a], bias);
+            f4 v = ln_apply(ln, mr[b], acc[a][b], cv[a], bias);
             if constexpr (EPI == EPI_F16) {
                 if (n < p.qcols) v = v * p.qscale;
             } else if constexpr (EPI == EPI_GELU_F16) {

@@ -209,20 +209,16 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
         go[c].store(c < 2 ? 1 : 0, std::memory_order_relaxed);
     }
     std::atomic<bool> abort_pack{false};
-    auto pack = [&](int t) {
-        for (int c = 0; c < n_chunks; c++) {
-            while (!go[c].load(std::memory_order_acquire)) {
-                if (abort_pack.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
-            }
-            const ChunkGeo & g = geo[c];
-            uint16_t * pin = (uint16_t *)hp.pin_in[c & 1];
-            for (int i = t; i < g.bc; i += P) {                 // image i of the chunk; pieces fill in order
-                cvt_f16(imgs[g.b0 + i].data, pin + per * i, per);
-                packed[c][(size_t)(i / g.fg) * g.ppg + (i % g.fg) / g.cp].fetch_add(1, std::memory_order_release);
-            }
+    // images t, t + step, ... of chunk c into its pinned buffer (the caller has made sure the buffer is free: go[c])
+    auto pack_chunk = [&](int c, int t, int step) {
+        const ChunkGeo & g = geo[c];
+        uint16_t * pin = (uint16_t *)hp.pin_in[c & 1];
+        for (int i = t; i < g.bc; i += step) {                  // image i of the chunk; pieces fill in order
+            cvt_f16(imgs[g.b0 + i].data, pin + per * i, per);
+            packed[c][(size_t)(i / g.fg) * g.ppg + (i % g.fg) / g.cp].fetch_add(1, std::memory_order_release);
         }
     };
+    const bool self_pack = P == 1;      // no helper threads: the driving thread packs chunk c itself, right before it enqueues it
     // the calling thread drives the device side; its share of the packing (t = 0) is done piecewise while it waits
     auto drive = [&]() {
         for (int c = 0; c < n_chunks && ok; c++) {
@@ -240,6 +236,9 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
                 ok = ok && hipStreamWaitEvent(hp.copy_stream, hp.ev_consumed[buf], 0) == hipSuccess;
             }
             hp.used[buf] = true;
+            // (the one-thread path used to pack EVERY chunk before driving any — with only two pinned buffers chunk c >= 2
+            // overwrote chunk c - 2 before its copies had been issued; now chunk c is packed here, behind the wait for its buffer)
+            if (self_pack && ok) pack_chunk(c, 0, 1);
             for (int gi = 0; gi < g.n_grp && ok; gi++) {
                 const int g0 = gi * g.fg, gn = std::min(g.fg, g.bc - g0);
                 for (int k = 0; k * g.cp < gn && ok; k++) {
@@ -265,8 +264,6 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
     };
     if (P == 1) {
         // no helpers: the caller packs a chunk, then drives it (no overlap inside a chunk; chunk c+1's pack still overlaps chunk c's forward)
-        for (int c = 0; c < n_chunks; c++) go[c].store(1, std::memory_order_relaxed);
-        pack(0);
         drive();
     } else {
         if (!hp.pool) hp.pool = new PackPool();
@@ -278,12 +275,7 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
                     if (abort_pack.load(std::memory_order_relaxed)) return;
                     std::this_thread::yield();
                 }
-                const ChunkGeo & g = geo[c];
-                uint16_t * pin = (uint16_t *)hp.pin_in[c & 1];
-                for (int i = t; i < g.bc; i += Pp) {
-                    cvt_f16(imgs[g.b0 + i].data, pin + per * i, per);
-                    packed[c][(size_t)(i / g.fg) * g.ppg + (i % g.fg) / g.cp].fetch_add(1, std::memory_order_release);
-                }
+                pack_chunk(c, t, Pp);
             }
         };
         hp.pool->run(P, [&](int idx) { if (idx == 0) drive(); else packer(idx - 1); });

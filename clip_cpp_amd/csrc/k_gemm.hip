@@ -339,27 +339,27 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         }
     }
     // LDS after the K loop: [0, BM * 272) the four waves' fp16 staging areas ((BM / 2) rows x 136 bytes each), then BM float2 of row statistics
-    LnRows<TM> lnr;
-    ln_rows_clear<TM>(lnr);
+    float2 * ln_rs = (float2 *)(smem_raw + ((BM * 272 + 15) & ~15));
     if constexpr (LNE) {
-        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)(smem_raw + ((BM * 272 + 15) & ~15)), ln_mine, tid, BM, wm * (BM / 2), frow, [] { __syncthreads(); });
+        if (ln) ln_rows_publish(ln_rs, ln_mine, tid, BM, [] { __syncthreads(); });
     }
+    const float2 * rs_lane = ln_rs + wm * (BM / 2) + frow;
     if constexpr ((EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) && BN == 128 && BM >= 128) {
         const int nb = n0 + wn * (BN / 2);
         if (nb + BN / 2 <= p.W.N && (p.ldc & 7) == 0) {                 // uniform per wave
             if ((nk & 1) && !ln) __syncthreads();                        // odd K-step count: the tail COMPUTE(0) had no barrier behind it
-            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, m0 + wm * (BM / 2), frow, fgrp, (half_t *)smem_raw + wave * (BM / 2) * 68, lane, ln, lnr);
+            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, m0 + wm * (BM / 2), frow, fgrp, (half_t *)smem_raw + wave * (BM / 2) * 68, lane, ln, rs_lane);
             return;
         }
     }
     if constexpr (EPI == EPI_RESID_F32 && BN == 128 && BM >= 128) {
         if (p.xg_out) {       // producer half of the fold: xg goes through the wave's staging area (full-line stores)
             if (nk & 1) __syncthreads();
-            gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp, false, lnr, (half_t *)smem_raw + wave * (BM / 2) * 68, lane);
+            gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp, false, rs_lane, (half_t *)smem_raw + wave * (BM / 2) * 68, lane);
             return;
         }
     }
-    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp, ln, lnr);
+    gemm_epilogue<EPI, TN, TM>(p, acc, n0 + wn * (BN / 2), m0 + wm * (BM / 2), frow, fgrp, ln, rs_lane);
 }
 
 template <int WT, int BM, int BN, int EPI>

@@ -246,25 +246,25 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     const int nb = n0 + wn * 128, mb = m0 + wm * 128;
     // LDS after the K loop: 4 fp16 staging areas of 128 rows x 136 bytes (69.6 KB), then 256 float2 of row statistics at 72 KB
     half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
-    LnRows<TM> lnr;                                    // LayerNorm folded into this GEMM: the row statistics once for both column halves
-    ln_rows_clear<TM>(lnr);
+    float2 * ln_rs = (float2 *)(smem + 72 * 1024);     // LayerNorm folded into this GEMM: (mean, rstd) of the tile's 256 rows
     if constexpr (LNE) {
-        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)(smem + 72 * 1024), ln_mine, tid, BM, wm * 128, frow, [] { __syncthreads(); });
+        if (ln) ln_rows_publish(ln_rs, ln_mine, tid, BM, [] { __syncthreads(); });
     }
+    const float2 * rs_lane = ln_rs + wm * 128 + frow;
     bool done = false;
     if constexpr (LNE) {
         if (nb + 128 <= p.W.N && (p.ldc & 7) == 0) {
             if (!ln) raw_barrier4();                   // every wave is done with the ring: it becomes the staging area
             typedef f4 half_acc_t[4][TM];
-            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane, ln, lnr);
-            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane, ln, lnr);
+            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane, ln, rs_lane);
+            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane, ln, rs_lane);
             done = true;
         }
     }
     if (!done) {
         const bool staged = EPI == EPI_RESID_F32 && p.xg_out != nullptr;
         if (staged) raw_barrier4();                    // producer half of the fold: xg goes through the staging areas
-        gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, lnr, staged ? stage : nullptr, lane);
+        gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, rs_lane, staged ? stage : nullptr, lane);
     }
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {

@@ -271,20 +271,20 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();
 #endif
     // LDS after the K loop: 8 fp16 staging areas of (TM * 16) rows x 136 bytes, then BM float2 of row statistics
-    LnRows<TM> lnr;
-    ln_rows_clear<TM>(lnr);
+    float2 * ln_rs = (float2 *)(smem + 8 * (TM * 16) * 136);
     if constexpr (LNE) {
-        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)(smem + 8 * (TM * 16) * 136), ln_mine, tid, BM, wm * TM * 16, frow, [] { __syncthreads(); });
+        if (ln) ln_rows_publish(ln_rs, ln_mine, tid, BM, [] { __syncthreads(); });
     }
+    const float2 * rs_lane = ln_rs + wm * TM * 16 + frow;
     half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
     bool done = false;
     if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
         if (nb + 64 <= p.W.N && (p.ldc & 7) == 0) {    // uniform per wave
-            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, stage, lane, ln, lnr);
+            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, stage, lane, ln, rs_lane);
             done = true;
         }
     }
-    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, lnr, stage, lane);
+    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, rs_lane, stage, lane);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();       // stores issued (not necessarily landed)

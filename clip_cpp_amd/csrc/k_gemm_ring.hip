@@ -375,11 +375,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();     // (before the final wait: the "epilogue" span includes it)
 #endif
     ring_wait_vmcnt<0>();      // nothing may land in this LDS allocation after the workgroup has left it
-    LnRows<TM> lnr;
-    ln_rows_clear<TM>(lnr);
     if constexpr (LNE) {
-        if (ln) ln_rows_exchange<TM>(lnr, (float2 *)smem, ln_mine, tid, RBM, wm * (RBM / WM), frow, [] { __syncthreads(); });
+        if (ln) ln_rows_publish((float2 *)smem, ln_mine, tid, RBM, [] { __syncthreads(); });
     }
+    const float2 * rs_lane = (const float2 *)smem + wm * (RBM / WM) + frow;
 #undef RING_ISSUE
 #undef RING_COMPUTE
 #undef RING_RAW
@@ -427,8 +426,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
                 }
         }
     }
-    if (ksplit == 1) gemm_epilogue_pre<EPI, TN, TM>(p, acc, bias_pre, resid_pre, nb_w, mb_w, frow, fgrp, ln, c_pre, lnr);
-    else gemm_epilogue<EPI, TN, TM>(p, acc, nb_w, mb_w, frow, fgrp, ln, lnr);
+    if (ksplit == 1) gemm_epilogue_pre<EPI, TN, TM>(p, acc, bias_pre, resid_pre, nb_w, mb_w, frow, fgrp, ln, c_pre, rs_lane);
+    else gemm_epilogue<EPI, TN, TM>(p, acc, nb_w, mb_w, frow, fgrp, ln, rs_lane);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();

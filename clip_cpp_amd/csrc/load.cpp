@@ -252,30 +252,58 @@ struct Loader {
 
 // File "<dir>/<basename>.<key>.hbm" = 32-byte header {magic, version, key, image bytes} + the HBM image.
 struct WeightCache {
-    static constexpr uint32_t kVersion = 2;    // bump when the device layout of any tensor changes (2: LayerNorm fold vectors)
+    static constexpr uint32_t kVersion = 3;    // bump when the device layout of any tensor changes (2: LayerNorm fold vectors)
     bool enabled = false, readable = false;
     std::string path;
     uint64_t key = 0, image_bytes = 0;
-    struct Header { char magic[8]; uint32_t version, reserved; uint64_t key, image_bytes; };
+    struct Header { char magic[8]; uint32_t version, plan_hash; uint64_t key, image_bytes; };   // plan_hash: offsets of every tensor in the image
+    uint32_t plan_hash = 0, file_plan_hash = 0;
 
     static uint64_t fnv(uint64_t h, const void * p, size_t n) {
         const uint8_t * b = (const uint8_t *)p;
         for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
         return h;
     }
+    // 8 bytes at a time (memcpy: tensor data is only 2-byte aligned in some files), multiply-xorshift: GB/s instead of FNV's byte loop
+    static uint64_t mix_words(uint64_t h, const void * p, size_t n) {
+        const uint8_t * b = (const uint8_t *)p;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, b + i, 8);
+            h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+        }
+        return i < n ? fnv(h, b + i, n - i) : h;
+    }
     void init(const GgufFile & g, const char * fname) {
         const char * dir = getenv("CLIP_AMD_WEIGHT_CACHE");
         if (!dir || !dir[0] || !g.file_base()) return;
-        // content identity: size, all metadata + tensor infos, the first and last 256 KB of tensor data, the layout version
+        // content identity: size, all metadata + tensor infos, the layout version, and the data of EVERY tensor — by default 16 blocks
+        // of 4 KB spread evenly over each tensor (first and last block included: ~13 MB hashed for ViT-L/14, a few ms; ADVICE r2: the
+        // first / last 256 KB of the file alone let a fine-tune or re-quantisation of inner layers collide), with
+        // CLIP_AMD_WEIGHT_CACHE_FULLHASH=1 every byte (word-wise mix: the file's pages are all read once).
         uint64_t h = 1469598103934665603ull;
         const uint64_t sz = g.file_size(), ver = kVersion;
         h = fnv(h, &sz, 8);
         h = fnv(h, &ver, 8);
         const size_t meta = (size_t)std::min<uint64_t>(g.data_offset, sz);
         h = fnv(h, g.file_base(), meta);
-        const size_t sample = (size_t)std::min<uint64_t>(256 << 10, sz - meta);
-        h = fnv(h, g.file_base() + meta, sample);
-        h = fnv(h, g.file_base() + sz - sample, sample);
+        const char * fh = getenv("CLIP_AMD_WEIGHT_CACHE_FULLHASH");
+        const bool full = fh && fh[0] == '1';
+        for (const GgufTensorInfo & t : g.tensors) {
+            if (!t.data || !t.nbytes) continue;
+            if (full) {
+                h = mix_words(h, t.data, t.nbytes);
+                continue;
+            }
+            constexpr size_t BLK = 4096, NB = 16;
+            if (t.nbytes <= BLK * NB) { h = mix_words(h, t.data, t.nbytes); continue; }
+            for (size_t b = 0; b < NB; b++) {
+                const size_t off = (size_t)((double)(t.nbytes - BLK) * (double)b / (double)(NB - 1)) & ~(size_t)7;
+                h = mix_words(h, t.data + off, BLK);
+            }
+        }
         key = h;
         const char * base = strrchr(fname, '/');
         char hex[24];
@@ -290,6 +318,7 @@ struct WeightCache {
             fstat(fileno(f), &st) == 0 && (uint64_t)st.st_size == sizeof hd + hd.image_bytes) {
             readable = true;
             image_bytes = hd.image_bytes;
+            file_plan_hash = hd.plan_hash;
         }
         fclose(f);
     }
@@ -308,7 +337,7 @@ struct WeightCache {
         if (!f) return;
         Header hd;
         memcpy(hd.magic, "CLAMDHBM", 8);
-        hd.version = kVersion; hd.reserved = 0; hd.key = key; hd.image_bytes = buf.size();
+        hd.version = kVersion; hd.plan_hash = plan_hash; hd.key = key; hd.image_bytes = buf.size();
         const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
         if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
     }
@@ -476,8 +505,15 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         Lp->st.plan_only = cache.readable;
         std::string why;
         if (!build(*Lp, why)) return fail(why);
+        {   // identity of the layout plan: where every tensor sits in the image (a layout change that keeps the total size must not read a stale cache)
+            uint64_t ph = 1469598103934665603ull;
+            for (const Fix & f : Lp->fixes) ph = WeightCache::fnv(ph, &f.off, sizeof f.off);
+            const uint64_t tot = Lp->st.size;
+            ph = WeightCache::fnv(ph, &tot, 8);
+            cache.plan_hash = (uint32_t)(ph ^ (ph >> 32));
+        }
         if (!Lp->st.plan_only) break;
-        if (cache.image_bytes == Lp->st.size) break;   // the cached image has the planned size: use it
+        if (cache.image_bytes == Lp->st.size && cache.file_plan_hash == cache.plan_hash) break;   // the cached image has the planned layout: use it
         cache.readable = false;                          // layout changed (another library version wrote it): rebuild and overwrite
     }
     Loader & L = *Lp;

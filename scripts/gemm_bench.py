@@ -41,6 +41,7 @@ only = [a for a in sys.argv[1:] if "." in a] + [a + "." for a in sys.argv[1:] if
 debug = [int(a[3:]) for a in sys.argv[1:] if a.startswith("dbg")] or [0]
 ITERS = int(os.environ.get("GEMM_ITERS", "20"))   # long runs (thousands) show the sustained, power-limited rate
 PRE = (1 << 16) if "pre" in sys.argv[1:] else 0   # 8-wave kernel: time the GEMM alone on an already dequantised fp16 panel (per-layer form)
+FOLD = (1 << 17) if "fold" in sys.argv[1:] else 0  # epilogues in their LayerNorm-fold form (consumer: fp16 epilogues; producer: residual epilogue)
 if "blas" in sys.argv[1:]:
     # yardstick: the vendor library (hipBLASLt / rocBLAS through torch) on the same shapes, plain f16 x f16 -> f16, no epilogue
     for name, M, N, K, epi in SHAPES:
@@ -66,6 +67,6 @@ for tname in types:
         row = []
         for tile in tiles:
             for dbg in debug:
-                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8) | PRE, tile, ITERS)
+                us = L.clip_amd_bench_gemm(TYPES[tname], N, K, M, epi | (dbg << 8) | PRE | FOLD, tile, ITERS)
                 row.append("%7d%s: %8.1f us %7.1f TF" % (tile, ("/d%d" % dbg) if dbg else "", us, 2.0 * M * N * K / us / 1e6 if us > 0 else -1))
         print("%-5s %-14s M=%6d N=%5d K=%5d | %s" % (tname, name, M, N, K, " | ".join(row)), flush=True)

@@ -314,6 +314,21 @@ def test_batches_beyond_one_workspace_chunk_and_stream_restore(gpu, fixture_cach
     assert np.array_equal(clip.encode_images(imgs[:5]), full[:5])
 
 
+@pytest.mark.parametrize("n_threads", [1, 2, 16])
+def test_host_api_with_one_thread_and_more_than_two_staging_chunks(gpu, fixture_cache, n_threads):
+    """with n_threads = 1 the host pipeline used to pack EVERY 256-image chunk before driving any, and with only two
+    pinned buffers chunk c >= 2 overwrote chunk c - 2 -> wrong images in the early rows of calls with more than 512 images.  Every row
+    of a 1030-image call must equal the same image in a small call, for one, two and many packing threads."""
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=False, vision=True)
+    clip = gpu.Clip(p, device=0)
+    imgs = fixtures.synthetic_images(1030, 32, seed=123)
+    full = clip.encode_images(imgs, n_threads=n_threads)
+    assert full.shape == (1030, 32) and np.all(np.isfinite(full))
+    for i0 in (0, 100, 252, 256, 508, 512, 768, 1020, 1026):
+        assert np.array_equal(clip.encode_images(imgs[i0:i0 + 4], n_threads=n_threads), full[i0:i0 + 4]), i0
+    assert np.array_equal(clip.encode_images(imgs, n_threads=16), full)
+
+
 def test_device_entry_points_with_torch_memory(gpu, fixture_cache):
     torch = pytest.importorskip("torch")
     p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")

@@ -295,6 +295,31 @@ def test_repacked_weight_cache_keyed_by_content(clip_lib, tmp_path, fixture_cach
     assert not c.weights_from_cache
     c.close()
     assert len(glob.glob(str(cache / "model_a.gguf.*.hbm"))) == 2
+    # same name, same size, same metadata, same first / last 256 KB — only a few bytes in the MIDDLE of an inner tensor differ
+    # (a fine-tune or re-quantisation of inner layers): every tensor is sampled, so this is another key, never the stale image
+    blob = bytearray(open(a, "rb").read())
+    lo, hi = int(len(blob) * 0.55) & ~4095, int(len(blob) * 0.75) & ~4095     # deep inside the tensor data (the metadata ends in the first quarter)
+    for off in range(lo, hi, 2048):                   # one byte per 2 KB over a fifth of the file: crosses sampled 4 KB blocks of the token table
+        blob[off] ^= 0x5A
+    third = tmp_path / "sub3"
+    third.mkdir()
+    (third / "model_a.gguf").write_bytes(bytes(blob))
+    c = clip_lib.Clip(str(third / "model_a.gguf"), verbosity=0)
+    assert not c.weights_from_cache
+    c.close()
+    assert len(glob.glob(str(cache / "model_a.gguf.*.hbm"))) == 3
+    monkeypatch.setenv("CLIP_AMD_WEIGHT_CACHE_FULLHASH", "1")      # every byte hashed: a single flipped byte anywhere is another key
+    blob2 = bytearray(open(a, "rb").read())
+    blob2[int(len(blob2) * 0.6)] ^= 1
+    fourth = tmp_path / "sub4"
+    fourth.mkdir()
+    (fourth / "model_a.gguf").write_bytes(bytes(blob2))
+    for path in (a, fourth / "model_a.gguf"):
+        c = clip_lib.Clip(str(path), verbosity=0)
+        assert not c.weights_from_cache                # (the full-hash key of `a` differs from its sampled key too)
+        c.close()
+    assert len(glob.glob(str(cache / "model_a.gguf.*.hbm"))) == 5
+    monkeypatch.delenv("CLIP_AMD_WEIGHT_CACHE_FULLHASH")
     # without the variable nothing is read or written
     monkeypatch.delenv("CLIP_AMD_WEIGHT_CACHE")
     c = clip_lib.Clip(str(a), verbosity=0)
