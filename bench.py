@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the text tower behind the vision tower on ONE stream (default: two contexts on two HIP streams, so "
                          "the small text kernels fill the tails of the vision kernels)")
+    ap.add_argument("--no-matrix", action="store_true", help="default config only: skip the other cells of the north_star matrix")
+    ap.add_argument("--matrix", action="store_true", help="run the matrix cells also with a non-default --config")
     ap.add_argument("--json-out", default=None)
     return ap.parse_args()
 
@@ -90,6 +92,18 @@ def kernel_source_sha16():
         if f.endswith(".hip") or f in ("kernels.h", "gemm_common.h", "attn_body.h"):    # everything that holds device code
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def weight_only_bytes(d, rep, dom):
+    """weight bytes per launch of the dominant kernel instantiation: N x K x bits / 8 from its shapes (MxNxK tags) — the 8(d) byte count."""
+    tot = n = 0
+    for k, v in rep.items():
+        if k.split("/")[0] != dom:
+            continue
+        M, N, K = (int(x) for x in k.split(":")[1].split("x"))
+        tot += v["launches"] * N * K * d.get("bits_per_weight", 4.5) / 8.0
+        n += v["launches"]
+    return tot / max(1, n)
 
 
 def algorithmic_work(vc, tc, ftype, n_img, text_lens):
@@ -113,6 +127,78 @@ def algorithmic_work(vc, tc, ftype, n_img, text_lens):
         wbytes = L * (4 * h * h + 2 * h * ff) * bpw + h * proj * bpw + tc["num_positions"] * h * bpw + (L * (9 * h + ff) + 2 * h) * 4
         by += wbytes + rows * (h * bpw + 4) + len(text_lens) * proj * 4     # token-embedding rows actually gathered + ids
     return fl, by
+
+
+def matrix_cell(torch, clip_cpp_amd, synth, cache, name, local_rank, steps=None, preheat=0.3, warmup=3):
+    """One cell of the north_star target matrix, measured like the headline (inputs resident in HBM, the two towers of a step on two
+    HIP streams, K timed steps between synchronisations) but rank-local and outside the headline's timed region."""
+    cfg = CONFIGS[name]
+    batch = cfg["batch"]
+    n_texts = batch if cfg["texts"] is None else cfg["texts"]
+    steps = steps or cfg["steps"]
+    path = synth.cached_model(cache, cfg["model"], cfg["ftype"], text=n_texts > 0, vision=True, seed=1234)
+    clip = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
+    vc, tc = clip.vision_config, clip.text_config
+    if n_texts == 0:
+        tc = dict(tc, num_positions=77)
+    S, proj = vc["image_size"], vc["projection_dim"]
+    stream = torch.cuda.Stream()
+    clip.set_stream(stream.cuda_stream)
+    clip_t = tstream = None
+    if n_texts:
+        clip_t = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
+        tstream = torch.cuda.Stream()
+        clip_t.set_stream(tstream.cuda_stream)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4242)
+    imgs = torch.randn((batch, S, S, 3), dtype=torch.float32, device="cuda", generator=g)
+    texts = synth.token_ids(n_texts, seed=11, min_len=1, max_len=min(75, tc["num_positions"] - 2))
+    flat = np.concatenate(texts).astype(np.int32) if n_texts else np.zeros(1, np.int32)
+    offsets = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
+    d_ids = torch.from_numpy(flat).cuda()
+    emb = torch.empty((batch + n_texts, proj), dtype=torch.float32, device="cuda")
+
+    def step():
+        with torch.cuda.stream(stream):
+            if tstream is not None:
+                tstream.wait_stream(stream)
+            clip.encode_images_device(imgs.data_ptr(), batch, emb[:batch].data_ptr(), True)
+            if n_texts:
+                clip_t.encode_texts_device(d_ids.data_ptr(), offsets, emb[batch:].data_ptr(), True)
+                stream.wait_stream(tstream)
+
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < preheat:
+        step()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(emb).all()), "non-finite embeddings in matrix cell %s" % name
+    fl, by = algorithmic_work(vc, tc, cfg["ftype"], batch, [len(t) for t in texts])
+    ms = dt / steps * 1e3
+    t_mfma, t_hbm = fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
+    out = {"name": name, "value": round((batch + n_texts) * steps / dt, 1), "unit": "embeddings/s" if n_texts else "images/s",
+           "ms_per_step": round(ms, 4), "steps": steps, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+           "t_bound_us": round(max(t_mfma, t_hbm) * 1e6, 2), "whole_step_frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 4)}
+    clip.close()
+    if clip_t is not None:
+        clip_t.close()
+    del imgs, emb
+    torch.cuda.empty_cache()
+    return out
+
+
+# the cells of the north_star matrix that the default run adds behind its timed region (VERDICT r2 item 3): the ViT-B/32 q4_0 column
+# on the headline's GGUF, then ViT-L/14 f16 if its synthetic model can be generated within the wall-time guard
+MATRIX_B32 = ["b32_q4_0_b1", "b32_q4_0_b32", "cfg2_b32_q4_0_b32_img"]
+MATRIX_L14 = ["l14_f16_b1", "l14_f16_b32", "l14_f16_b256"]
+L14_GEN_GUARD_S = 60.0
 
 
 def main():
@@ -275,6 +361,7 @@ def main():
         if inst:
             dom = max(inst, key=lambda k: inst[k]["ms"])
             d = inst[dom]
+            d["bits_per_weight"] = BITS_PER_WEIGHT[cfg["ftype"]]
             avg_ms = d["ms"] / d["launches"]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in rep.values())
@@ -303,6 +390,11 @@ def main():
             hbm_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
             main, other = (hbm_view, mfma_view) if t_hbm > t_mfma else (mfma_view, hbm_view)
             roofline = dict(main)
+            # intermediates are not algorithmic, so a weight GEMM at batch >= 2 is MFMA-bound and the fraction that follows
+            # is the MFMA view; `frac` above keeps the stricter of the two kernel-level views (the HBM view counts the activation and
+            # residual bytes the launch really moves)
+            roofline["frac_8d"] = mfma_view["frac"] if fl_l / max(1.0, weight_only_bytes(d, rep, dom)) > 310.0 else hbm_view["frac"]
+            roofline["frac_8d_note"] = "SURVEY 8(d) view: algorithmic FLOPs / 2.5 PFLOP/s when FLOPs per WEIGHT byte exceed the ridge (310 FLOP/B), else weight bytes / 8 TB/s"
             roofline.update({"kernel": dom + " (fp16 MFMA weight GEMM; template args as in the rocprofv3 kernel name)",
                              "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
                              "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l,
@@ -372,6 +464,29 @@ def main():
             cpu_baseline["gpu_vs_cpu_text_1_minus_cos_max"] = float(cosd_t.max())
             cpu_baseline["gpu_vs_cpu_text_1_minus_cos_mean"] = float(cosd_t.mean())
 
+    matrix = None
+    if rank == 0 and N == 1 and not args.no_matrix and ((args.config == "b32_q4_0_b256" and not custom) or args.matrix):
+        matrix = []
+        clip.close()
+        if overlap:
+            clip_t.close()
+        del imgs, emb
+        torch.cuda.empty_cache()
+        for name in MATRIX_B32:
+            matrix.append(matrix_cell(torch, clip_cpp_amd, synth, cache, name, local_rank))
+        t_gen = time.perf_counter()
+        try:
+            synth.cached_model(cache, "l14", "f16", text=True, vision=True, seed=1234)
+            gen_s = time.perf_counter() - t_gen
+        except Exception as e:   # noqa: BLE001
+            gen_s = None
+            matrix.append({"name": "l14_f16_*", "skipped": "synthetic ViT-L/14 f16 model could not be generated: %s" % e})
+        if gen_s is not None and gen_s > L14_GEN_GUARD_S:
+            matrix.append({"name": "l14_f16_*", "skipped": "generating the synthetic ViT-L/14 f16 GGUF took %.0f s (> %.0f s guard)" % (gen_s, L14_GEN_GUARD_S)})
+        elif gen_s is not None:
+            for name in MATRIX_L14:
+                matrix.append(matrix_cell(torch, clip_cpp_amd, synth, cache, name, local_rank, steps=3 if name.endswith("b256") else None))
+
     if rank == 0:
         workload = "CLIP ViT-%s %s %s: %d images (%dx%d, vision tower)%s per GPU per step, inputs resident in HBM, %s, RCCL all-gather of final embeddings when N>1" % (
             cfg["model"].upper(), cfg["ftype"], "two-tower" if n_texts else "vision tower only", batch, S, S,
@@ -387,7 +502,7 @@ def main():
             "images_per_s_per_gpu": round(img_rate, 1), "texts_per_s_per_gpu": round(txt_rate, 1),
             "host_api_images_per_s": host_api,
             "host_api_images_per_s_4x_batch_per_call": host_api_x4,
-            "roofline": roofline, "whole_step_roofline": whole, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "whole_step_roofline": whole, "cpu_baseline": cpu_baseline, "matrix": matrix, "kernels": kernels,
             "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)",
         }
         line = json.dumps(out)

@@ -136,7 +136,20 @@ bool skinny_enabled() {
     return on != 0;
 }
 
-void skinny(clip_ctx * ctx, const char * what, const SkinnyParams & p, int epi) {
+#ifdef CLIPAMD_SK_TIMING   // tuning builds (scripts/build_sk_timing.sh): per-launch phase stamps of the small-M kernels
+unsigned long long * g_sk_stamps = nullptr;
+int g_sk_stamp_launch = 0;
+constexpr int SK_STAMP_LAUNCHES = 512;
+#endif
+
+void skinny(clip_ctx * ctx, const char * what, const SkinnyParams & p0, int epi) {
+#ifdef CLIPAMD_SK_TIMING
+    SkinnyParams p = p0;
+    if (!g_sk_stamps && hipMalloc((void **)&g_sk_stamps, SK_STAMP_LAUNCHES * 16 * 8) == hipSuccess) (void)hipMemset(g_sk_stamps, 0, SK_STAMP_LAUNCHES * 16 * 8);
+    if (g_sk_stamps) p.stamps = g_sk_stamps + (size_t)(g_sk_stamp_launch++ % SK_STAMP_LAUNCHES) * 16;
+#else
+    const SkinnyParams & p = p0;
+#endif
     if (!ctx->profiling) { launch_skinny(p, epi, ctx->stream); return; }
     char fam[96];
     // tag = kernel instantiation as rocprofv3 prints it: skinny_kernel<WT, MF, NW, EPI, LNA> (MF = 1; 8 waves for the long-K residual / patch GEMMs)
@@ -645,3 +658,15 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
 }
 
 }  // namespace clipamd
+
+#ifdef CLIPAMD_SK_TIMING
+// the stamps of the last forward's small-M launches (16 x u64 per launch, launch order), restarting the launch counter
+extern "C" int clip_amd_debug_read_sk_stamps(unsigned long long * out, int cap_launches) {
+    using namespace clipamd;
+    (void)hipDeviceSynchronize();
+    const int n = g_sk_stamp_launch < cap_launches ? g_sk_stamp_launch : cap_launches;
+    if (g_sk_stamps && n > 0) (void)hipMemcpy(out, g_sk_stamps, (size_t)n * 16 * 8, hipMemcpyDeviceToHost);
+    g_sk_stamp_launch = 0;
+    return n;
+}
+#endif

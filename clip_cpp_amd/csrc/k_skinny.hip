@@ -67,6 +67,16 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
     int mrow[MF];
 #pragma unroll
     for (int b = 0; b < MF; b++) { const int m = m_base + b * 16 + frow; mrow[b] = m < p.M ? m : p.M - 1; }
+#ifdef CLIPAMD_SK_TIMING   // tuning builds: phase stamps (shader clock; [6]/[7] the 100 MHz real-time clock) of the first and the last workgroup
+    const bool sk_first = blockIdx.x == 0 && blockIdx.y == 0, sk_last = blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
+    const bool stamper = p.stamps && tid == 0 && (sk_first || sk_last);
+    unsigned long long * stamp = p.stamps + (sk_first ? 0 : 8);
+#define SK_STAMP(i_) if (stamper) stamp[i_] = __builtin_amdgcn_s_memtime()
+    if (stamper) stamp[6] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SK_STAMP(i_)
+#endif
+    SK_STAMP(0);
 
     // ---- operand loaders (one k-block = one 16 x 32 weight fragment + MF 16 x 32 activation fragments)
     struct WReg { WFrag<WT> q; h8 h; };
@@ -120,6 +130,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         }
     }
 
+    SK_STAMP(1);           // first chunk + epilogue operands requested
     float mean[MF], rstd[MF];
     if constexpr (LNA) {
         // gamma / beta of the whole row into LDS once (one 16-byte load per thread and array for K <= 1024)
@@ -159,6 +170,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         for (int b = 0; b < MF; b++) { const float2 st = lnst[b * 16 + frow]; mean[b] = st.x; rstd[b] = st.y; }
     }
 
+    SK_STAMP(2);           // LayerNorm prologue done (statistics round trip + barrier)
     f4 acc[MF];
 #pragma unroll
     for (int b = 0; b < MF; b++) acc[b] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -189,10 +201,12 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
 #undef SK_LOAD
 #undef SK_COMPUTE
 
+    SK_STAMP(3);           // all MFMAs issued (the loads of every chunk have landed)
     // ---- intra-workgroup split-K: partial fragments through LDS, summed in wave order
 #pragma unroll
     for (int b = 0; b < MF; b++) red[(wave * MF + b) * 64 + lane] = acc[b];
     __syncthreads();
+    SK_STAMP(4);           // partial sums exchanged
     for (int b = wave; b < MF; b += NW) {
         f4 v = red[b * 64 + lane];
         for (int w = 1; w < NW; w++) v = v + red[(w * MF + b) * 64 + lane];
@@ -237,6 +251,14 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
             if (ok) *(uint2 *)((half_t *)p.out + (size_t)m * p.ldc + n) = make_uint2(h2u(lo), h2u(hi));
         }
     }
+#ifdef CLIPAMD_SK_TIMING
+    SK_STAMP(5);           // stores issued
+    if (stamper) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#undef SK_STAMP
 }
 
 template <int WT, int MF, int NW, int EPI, bool LNA>

@@ -163,6 +163,7 @@ struct SkinnyParams {
     const float * pos = nullptr;
     float2 * stats_out = nullptr;        // EPI_RESID_F32: [row][stats_cap], entry blockIdx.x = statistics of the row over this workgroup's 16 columns
     int stats_cap = 128;
+    unsigned long long * stamps = nullptr;   // -DCLIPAMD_SK_TIMING builds (scripts/build_sk_timing.sh): 16 phase stamps of the first and the last workgroup
 };
 constexpr int SKINNY_MAX_ROWS = 512;    // rows the statistics buffers are sized for ([2][SKINNY_MAX_ROWS][stats_cap] float2)
 bool skinny_supported(const SkinnyParams & p, int epilogue);

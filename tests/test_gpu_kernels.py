@@ -617,3 +617,38 @@ def test_lnfold_model_shapes_heuristic_tiles(L, tname, M, h, K1, N2, epi2):
     assert bad.size == 0, "%d/%d bad, max err %g" % (len(bad), yb.size, err.max())
     rel = np.linalg.norm(yb - want) / np.linalg.norm(want)
     assert rel < 2e-3, rel
+
+
+# ---- the large-M kernels against float64 AT the sizes they run at (so far bit-identity to the 64 x 64 tile at
+# M <= 5000 and self-consistency at real size) ----
+@pytest.mark.parametrize("tname", ["f16", "q5_1"])
+@pytest.mark.parametrize("M,N,K", [(33410, 1024, 1024), (65792, 1024, 1024), (65792, 4096, 1024)])
+def test_large_m_kernels_vs_float64_at_model_size(L, tname, M, N, K):
+    """ViT-L/14 at batch 130 / 256 (33410 / 65792 token rows; reference clip.cpp:1360-1422): the heuristic's choice there — 256 x 256
+    four-wave tiles on the whole rounds + a second launch for the remaining rows (k_gemm4.hip), block-quantised weights through the
+    fp16 panel — and the 8-wave 160 x 256 kernel, against the float64 product of the fp16-rounded activations with the dequantised
+    weights, elementwise (bound = fp16 rounding of the dequantised weight), every row of the batch."""
+    assert L.clip_amd_test_gemm_tile(M, N, K, int(tname != "f16")) % 1000 in (259, 260)      # the regime under test
+    rng = np.random.default_rng(M + N + K)
+    tid = ref.GGML_TYPES[tname]
+    raw = ref.quantize(tid, _weights(rng, N, K))
+    Wd = ref.dequantize(tid, raw, N, K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    Xh = _h(X)
+    ys = {tile: run_gemm(L, tid, raw, N, K, X, bias=bias, epi=0, tile=tile) for tile in (0, 160256)}
+    Wt64, Wabs = Wd.astype(np.float64).T.copy(), np.abs(Wd).T.copy()
+    for r0 in range(0, M, 8192):                              # float64 reference in row chunks (2 GB for the largest shape otherwise)
+        r1 = min(M, r0 + 8192)
+        want = Xh[r0:r1].astype(np.float64) @ Wt64 + bias
+        bound = 1.0e-3 * (np.abs(Xh[r0:r1]) @ Wabs).astype(np.float64) + 1e-5
+        for tile, y in ys.items():
+            err = np.abs(y[r0:r1] - want)
+            bad = np.argwhere(err > bound)
+            assert bad.size == 0, "tile %d rows %d..%d: %d bad, first %s got %g want %g" % (
+                tile, r0, r1, len(bad), bad[0], y[r0 + bad[0][0], bad[0][1]], want[tuple(bad[0])])
+    assert np.array_equal(ys[0], ys[160256]), _diff_report(ys[160256], ys[0])      # and the two kernels agree bit for bit
+    if N == K:       # the residual epilogue of the same kernels (out-projection shape), in place as the layers run it
+        resid = rng.standard_normal((M, N)).astype(np.float32)
+        yr = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=4)
+        assert np.array_equal(yr, resid + ys[0]) or np.max(np.abs(yr - (resid + ys[0]))) <= 1e-6 * np.max(np.abs(resid))

@@ -16,6 +16,13 @@ from oracle import fixtures, ref
 pytestmark = pytest.mark.gpu
 
 TOL = {"f32": 1e-4, "f16": 1e-4, "q4_0": 1e-3, "q4_1": 1e-3, "q5_0": 1e-3, "q5_1": 1e-3, "q8_0": 1e-3}
+# What the tests at MODEL shape (ViT-B/32, L/14, H/14 widths) assert: the observed maxima are 1.0e-4 (images) / 1.9e-4 (texts) for q4_0
+# and below 1e-5 for f16 files, so a regression that triples the error must fail; TOL stays the documented contract
+# and is what the 32-128-wide test towers are held to (one rounding flip is a larger share of their embeddings).
+TOL_MODEL = {"f32": 3e-5, "f16": 3e-5, "q4_0": 3e-4, "q4_1": 3e-4, "q5_0": 3e-4, "q5_1": 3e-4, "q8_0": 3e-4}
+# text towers: the one-token text (a bare BOS, a single row through 12 layers) sits at 4.4e-4 against the oracle's 8-bit activations
+# (ViT-B/32 q8_0, r03d), every longer text below 1.7e-4
+TOL_MODEL_TEXT = {k: (6e-4 if k.startswith("q") else v) for k, v in TOL_MODEL.items()}
 
 
 @pytest.fixture(scope="module")
@@ -95,14 +102,14 @@ def test_text_tower_parity_at_model_shape(gpu, fixture_cache, config, ftype, n_t
         assert batch.shape == (n_texts, clip.text_config["projection_dim"]) and np.all(np.isfinite(batch))
         want = np.stack([orc.text_encode(ids, normalize=normalize, mode=ref.MODE_FAITHFUL) for ids in texts])
         d = one_minus_cos(batch, want)
-        assert np.all(d <= TOL[ftype]), (config, ftype, normalize, float(d.max()), int(d.argmax()), len(texts[int(d.argmax())]))
+        assert np.all(d <= TOL_MODEL_TEXT[ftype]), (config, ftype, normalize, float(d.max()), int(d.argmax()), len(texts[int(d.argmax())]))
         if not normalize:
             np.testing.assert_allclose(np.linalg.norm(batch, axis=1), np.linalg.norm(want, axis=1), rtol=2e-2)
     batch = clip.encode_texts(texts, normalize=True)
     assert np.array_equal(batch, clip.encode_texts(texts, normalize=True))                      # deterministic
     for i in list(range(9)) + [n_texts - 1]:
         single = np.asarray(clip.encode_text(list(texts[i]), normalize=True), dtype=np.float32)
-        assert one_minus_cos(single, want_n(orc, texts[i])) <= TOL[ftype], i
+        assert one_minus_cos(single, want_n(orc, texts[i])) <= TOL_MODEL_TEXT[ftype], i
         # batch row == the text alone, up to the fp32 re-association of a different GEMM schedule (split-K at small M)
         assert one_minus_cos(single, batch[i]) <= 1e-6, (i, len(texts[i]))
         np.testing.assert_allclose(batch[i], single, atol=3e-4)
@@ -171,10 +178,24 @@ def test_vit_b32_q4_0_batch_parity(gpu, fixture_cache):
     got = clip.encode_images(imgs)
     want = orc.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL)
     d = one_minus_cos(got, want)
-    assert np.all(d <= 1e-3), d
+    assert np.all(d <= TOL_MODEL["q4_0"]), d
     ideal = orc.image_batch_encode(imgs, mode=ref.MODE_IDEAL)
     # the GPU (fp16 activations, exact weights) should sit closer to the ideal network than ggml's q8 activations do
     assert np.median(one_minus_cos(got, ideal)) <= np.median(one_minus_cos(want, ideal)) * 1.5 + 1e-6
+
+
+def test_baseline_config2_32_images_vs_oracle(gpu, fixture_cache):
+    """BASELINE config 2 itself: 32 ViT-B/32 q4_0 images = 1600 token rows, i.e. the mid-M ring kernel (q/k/v, out-projection, FFN-down)
+    and the 160 x 128 tile (FFN-up) with the LayerNorm fold, every image against the oracle in ggml-faithful numerics
+    (reference clip.cpp:1247-1523).  Observed maximum 1.0e-4 (bench sample): asserted at 3e-4, the documented contract stays 1e-3."""
+    p = fixtures.cached_model(fixture_cache, "b32", "q4_0", text=False, vision=True)
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(32, 224, seed=202)
+    got = clip.encode_images(imgs)
+    want = orc.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL)
+    d = one_minus_cos(got, want)
+    assert np.all(d <= TOL_MODEL["q4_0"]), d.max()
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
 
 
 def test_full_size_properties_b32_q4_0_batch256(gpu, fixture_cache):
@@ -250,7 +271,7 @@ def test_vit_l14_f16_shapes(gpu, fixture_cache):
     got = clip.encode_images(imgs)
     want = orc.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL)
     d = one_minus_cos(got, want)
-    assert np.all(d <= 1e-4), d
+    assert np.all(d <= TOL_MODEL["f16"]), d
 
 
 @pytest.mark.parametrize("config,ftype", [("l14", "q5_1"), ("h14", "q8_0")])
@@ -262,7 +283,7 @@ def test_large_model_shapes_quantised(gpu, fixture_cache, config, ftype):
     imgs = fixtures.synthetic_images(3, 224, seed=31)
     got = clip.encode_images(imgs)
     want = orc.image_batch_encode(imgs[:1], mode=ref.MODE_FAITHFUL)
-    assert one_minus_cos(got[:1], want)[0] <= TOL[ftype], one_minus_cos(got[:1], want)
+    assert one_minus_cos(got[:1], want)[0] <= TOL_MODEL[ftype], one_minus_cos(got[:1], want)
     assert one_minus_cos(clip.encode_images(imgs[:1]), got[:1])[0] <= 1e-6
 
 
