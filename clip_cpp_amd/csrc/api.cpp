@@ -628,7 +628,7 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
     const int st_stride = (int)((M + 63) & ~(int64_t)63);
     DBuf da32((size_t)M * K1 * 4), da16((size_t)(M + 1) * W1.Kpad * 2), dx((size_t)M * h * 4), dxn((size_t)(M + 1) * W2.Kpad * 2), dy16((size_t)M * N2 * 2),
         dy32((size_t)M * N2 * 4), db1((size_t)h * 4), db2((size_t)N2 * 4), dg((size_t)h * 4), dbeta((size_t)h * 4), dc((size_t)N2 * 4), dbf((size_t)N2 * 4),
-        dstats((size_t)(h / 32) * st_stride * 8);
+        dstats((size_t)(h / 16) * st_stride * 8);
     hipStream_t s = nullptr;
     (void)hipMemcpy(da32.p, a, (size_t)M * K1 * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dx.p, resid, (size_t)M * h * 4, hipMemcpyHostToDevice);
@@ -653,6 +653,40 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
     p2.A = (const half_t *)dxn.p; p2.lda = W2.Kpad; p2.M = (int)M; p2.W = W2; p2.out = dy16.p; p2.ldc = (int)N2; p2.qcols = qcols; p2.qscale = qscale;
     common(p2, panel2, W2);
     const int epi = epi2 == 1 ? EPI_F16 : epi2 == 2 ? EPI_GELU_F16 : EPI_QGELU_F16;
+    if (tile1 < 0) {
+        // the small-M kernels (k_skinny.hip; M <= 64 in the layers, the hook allows up to 128): folded form, or LayerNorm fused on the operand
+        if (M > 128 || h > 2048) { (void)hipFree(w1base); (void)hipFree(w2base); return -5; }
+        DBuf dskst((size_t)2 * SKINNY_MAX_ROWS * 128 * sizeof(float2));
+        SkinnyParams a1;
+        a1.A16 = (const half_t *)da16.p; a1.lda = W1.Kpad; a1.M = (int)M; a1.W = W1; a1.bias = (const float *)db1.p; a1.out = dx.p; a1.ldc = (int)h; a1.resid = (const float *)dx.p;
+        SkinnyParams a2;
+        a2.M = (int)M; a2.W = W2; a2.out = dy16.p; a2.ldc = (int)N2; a2.qcols = qcols; a2.qscale = qscale; a2.eps = eps;
+        if (fold) {
+            launch_fold_vectors(W2, (const float *)dg.p, (const float *)dbeta.p, (const float *)db2.p, (float *)dc.p, (float *)dbf.p, s);
+            a1.xg_out = (half_t *)dxn.p; a1.ldxg = W2.Kpad; a1.xg_gamma = (const float *)dg.p; a1.fstats_out = (float2 *)dstats.p; a1.fstride_out = st_stride;
+            a2.A16 = (const half_t *)dxn.p; a2.lda = W2.Kpad; a2.bias = (const float *)dbf.p; a2.ln_c = (const float *)dc.p;
+            a2.fstats = (const float2 *)dstats.p; a2.fslots = (int)h / 16; a2.fslotw = 16; a2.fstride = st_stride;
+        } else {
+            a1.stats_out = (float2 *)dskst.p;
+            a2.x32 = (const float *)dx.p; a2.ldx = (int)h; a2.ln_w = (const float *)dg.p; a2.ln_b = (const float *)dbeta.p; a2.stats_in = (const float2 *)dskst.p;
+            a2.stats_slots = (int)h / 16; a2.bias = (const float *)db2.p;
+        }
+        int rc2 = 0;
+        if (!skinny_supported(a1, EPI_RESID_F32) || !skinny_supported(a2, epi)) rc2 = -5;
+        else {
+            launch_skinny(a1, EPI_RESID_F32, s);
+            launch_skinny(a2, epi, s);
+            launch_f16_to_f32((const half_t *)dy16.p, (int)N2, (float *)dy32.p, (int)N2, (int)M, (int)N2, s);
+            if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc2 = -4;
+            else {
+                (void)hipMemcpy(x1_out, dx.p, (size_t)M * h * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(y_out, dy32.p, (size_t)M * N2 * 4, hipMemcpyDeviceToHost);
+            }
+        }
+        (void)hipFree(w1base);
+        (void)hipFree(w2base);
+        return rc2;
+    }
     if (fold) {
         launch_fold_vectors(W2, (const float *)dg.p, (const float *)dbeta.p, (const float *)db2.p, (float *)dc.p, (float *)dbf.p, s);
         p1.xg_out = (half_t *)dxn.p; p1.ldxg = W2.Kpad; p1.xg_gamma = (const float *)dg.p; p1.stats_out = (float2 *)dstats.p; p1.stats_stride = st_stride;

@@ -214,6 +214,56 @@ bool run_layers_skinny(clip_ctx * ctx, const DevTower & tw, int rows, int h, int
     return true;
 }
 
+// The small-M chain with the LayerNorm folded (kernels.h SkinnyParams::ln_c / xg_out): 5 launches per layer as above, but the q/k/v and
+// FFN-up kernels read the fp16 operand xn = fp16(x gamma) the residual epilogues leave (half the bytes of the f32 rows, no gamma / beta
+// staging, no normalisation in registers) and finish the LayerNorm in their epilogue.  r03 stamps: the LayerNorm prologue was 2.7 us of
+// the 6-7 us these two kernels live.  Precondition as run_layers_fold: xn and ONE statistics slot per row from the entry kernel.
+bool run_layers_skinny_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
+                            const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid,
+                            float2 * stats, int stats_stride) {
+    hipStream_t s = ctx->stream;
+    const int dh = h / nh;
+    const float qscale = 1.0f / sqrtf((float)dh);
+    const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    int slots = 1, slotw = h;
+    auto consume = [&](SkinnyParams & p, const float * c, const float * bf) {
+        p.A16 = xn; p.lda = h; p.bias = bf; p.ln_c = c; p.fstats = stats; p.fslots = slots; p.fslotw = slotw; p.fstride = stats_stride; p.eps = eps;
+    };
+    auto produce = [&](SkinnyParams & p, const float * gamma_next) {
+        if (!gamma_next) return;
+        p.xg_out = xn; p.ldxg = h; p.xg_gamma = gamma_next; p.fstats_out = stats; p.fstride_out = stats_stride;
+        slots = h / 16; slotw = 16;
+    };
+    for (size_t li = 0; li < tw.layers.size(); li++) {
+        const DevLayer & l = tw.layers[li];
+        SkinnyParams q;   // q/k/v projection of the folded LN1 (+ Q scale after the bias, clip.cpp:1363)
+        q.M = rows; q.W = l.qkv; q.out = qkv; q.ldc = 3 * h; q.qscale = qscale; q.qcols = h;
+        consume(q, l.qkv_c, l.qkv_bf);
+        skinny(ctx, "ln1_qkv", q, EPI_F16);
+        {
+            const double afl = 4.0 * (double)nseq * nh * (double)max_len * max_len * dh;
+            ProfScope ps(ctx, "attention", nseq * nh, max_len, dh, afl, (double)rows * h * 8);
+            if (!launch_attention(qkv, att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s)) {
+                fprintf(stderr, "clip (hip): attention kernel does not support T=%d d_head=%d\n", max_len, dh);
+                return false;
+            }
+        }
+        SkinnyParams o;   // out-projection + residual; leaves xn = fp16(x ln2_w) and the 16-column statistics for LN2
+        o.A16 = att; o.lda = h; o.M = rows; o.W = l.o; o.bias = l.o_b; o.out = x; o.ldc = h; o.resid = x;
+        produce(o, l.ln2_w);
+        skinny(ctx, "out_resid", o, EPI_RESID_F32);
+        SkinnyParams u;   // FFN-up of the folded LN2 + activation
+        u.M = rows; u.W = l.ff1; u.out = mid; u.ldc = ff;
+        consume(u, l.ff1_c, l.ff1_bf);
+        skinny(ctx, "ln2_ffn_up", u, act);
+        SkinnyParams d;   // FFN-down + residual; operand and statistics for the next layer's LN1
+        d.A16 = mid; d.lda = ff; d.M = rows; d.W = l.ff2; d.bias = l.ff2_b; d.out = x; d.ldc = h; d.resid = x;
+        produce(d, li + 1 < tw.layers.size() ? tw.layers[li + 1].ln1_w : nullptr);
+        skinny(ctx, "ffn_down_resid", d, EPI_RESID_F32);
+    }
+    return true;
+}
+
 // L x { LN1, QKV, attention, out-proj(+res), LN2, FFN-up(+act), FFN-down(+res) }   (clip.cpp:1342-1423 / :1064-1143)
 bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
                 const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid) {
@@ -471,11 +521,11 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
         const int Bc = std::min(chunk, B - b0);
         const int rows = Bc * T;
         Carver sizer(nullptr);
-        const int st_stride = (rows + 63) & ~63;               // LayerNorm-fold statistics: [h / 32 slots][st_stride rows] float2
+        const int st_stride = (rows + 63) & ~63;               // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
         float2 * stats = nullptr;
         auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& col,
                          half_t *& pooled, float *& emb) {
-            stats = c.take<float2>((size_t)(h / 32) * st_stride);
+            stats = c.take<float2>((size_t)(h / 16) * st_stride);
             x = c.take<float>((size_t)rows * h);
             xn = c.take<half_t>((size_t)rows * h);
             qkv = c.take<half_t>((size_t)rows * 3 * h);
@@ -505,14 +555,16 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
         gemm(ctx, "gemm_patch", pp, EPI_PATCH_F32);
         launch_cls_rows(x, V.class_embd, V.pos, Bc, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
         const bool skinny = layers_fit_skinny(V, rows, h, ff);
-        const bool fold = !skinny && ctx->ln_fold && !V.layers.empty();
+        const bool fold = ctx->ln_fold && !V.layers.empty();
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
             if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
                 launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, xn, h, stats, s);
             else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
         }
-        if (skinny) {
+        if (skinny && fold) {
+            if (!run_layers_skinny_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid, stats, st_stride)) return false;
+        } else if (skinny) {
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, qkv, att, mid)) return false;
         } else if (fold) {
@@ -553,11 +605,11 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         }
         max_len = std::max(max_len, len);
     }
-    const int st_stride = (rows + 63) & ~63;                   // LayerNorm-fold statistics: [h / 32 slots][st_stride rows] float2
+    const int st_stride = (rows + 63) & ~63;                   // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
     float2 * stats = nullptr;
     auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& pooled,
                      float *& emb, int *& seq, int *& last) {
-        stats = c.take<float2>((size_t)(h / 32) * st_stride);
+        stats = c.take<float2>((size_t)(h / 16) * st_stride);
         x = c.take<float>((size_t)rows * h);
         xn = c.take<half_t>((size_t)rows * h);
         qkv = c.take<half_t>((size_t)rows * 3 * h);
@@ -605,11 +657,13 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     }
     auto launch_all = [&]() -> bool {
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
-        const bool fold = !skinny && ctx->ln_fold && !Tw.layers.empty();
+        const bool fold = ctx->ln_fold && !Tw.layers.empty();
         if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
             launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats);
         else launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
-        if (skinny) {
+        if (skinny && fold) {
+            if (!run_layers_skinny_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride)) return false;
+        } else if (skinny) {
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, qkv, att, mid)) return false;
         } else if (fold) {

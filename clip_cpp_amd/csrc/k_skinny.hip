@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
                                                       // of loads per lane: the whole K range of a wave at K = 768 / 1024 (and at K = 3072
                                                       // with 8 waves and one fragment row)
     __shared__ f4 red[NW * MF * 64];
-    __shared__ float2 lnst[LNA ? 128 : 1];
+    constexpr bool FOLDC = !LNA && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16);   // can consume a folded LayerNorm (p.ln_c)
+    __shared__ float2 lnst[(LNA || FOLDC) ? 128 : 1];
     __shared__ float lng[LNA ? 2048 : 1], lnb[LNA ? 2048 : 1];
 
     const int tid = threadIdx.x;
@@ -121,10 +122,13 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
     // so do the epilogue's operands (bias, residual) of the fragment row this wave will finalise: nothing in the tail of the
     // kernel waits for memory any more
     static_assert(MF <= NW, "each wave finalises at most one fragment row");
-    f4 bias_pre = (f4){0.f, 0.f, 0.f, 0.f}, resid_pre = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 bias_pre = (f4){0.f, 0.f, 0.f, 0.f}, resid_pre = (f4){0.f, 0.f, 0.f, 0.f}, c_pre = (f4){0.f, 0.f, 0.f, 0.f}, gam_pre = (f4){0.f, 0.f, 0.f, 0.f};
+    const bool foldc = FOLDC && p.ln_c != nullptr;
     {
         const int n = n0 + fgrp * 4, m = m_base + wave * 16 + frow;
         if (EPI != EPI_PATCH_F32 && p.bias && n < p.W.N) bias_pre = *(const f4 *)(p.bias + n);
+        if constexpr (FOLDC) { if (foldc && n < p.W.N) c_pre = *(const f4 *)(p.ln_c + n); }
+        if constexpr (EPI == EPI_RESID_F32) { if (p.xg_out && n < p.W.N) gam_pre = *(const f4 *)(p.xg_gamma + n); }
         if constexpr (EPI == EPI_RESID_F32) {
             if (wave < MF && m < p.M && n < p.W.N) resid_pre = *(const f4 *)(p.resid + (size_t)m * p.ldc + n);
         }
@@ -170,6 +174,50 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         for (int b = 0; b < MF; b++) { const float2 st = lnst[b * 16 + frow]; mean[b] = st.x; rstd[b] = st.y; }
     }
 
+    if constexpr (FOLDC) {
+        if (foldc) {
+            // LayerNorm folded into this GEMM: (mean, rstd) of the workgroup's 16 rows from the partial statistics — 16 threads per row,
+            // thread `sub` takes slots sub, sub + 16, ... (all in flight with the operand loads above), Chan merges in a fixed order:
+            // sequential inside a thread, then a butterfly over the 16 lanes, lower lane first.  Read back in the epilogue, behind the
+            // barrier of the partial-sum exchange.
+            constexpr int TPR = (NW * 64) / (MF * 16);
+            static_assert(TPR == 16 || TPR == 32, "16 or 32 threads per row");
+            const int r = tid / TPR, sub = tid % TPR;
+            const int gr = m_base + r;
+            const float2 * st = p.fstats + (gr < p.M ? gr : p.M - 1);
+            const float w = (float)p.fslotw, invw = 1.0f / w;
+            float n_ = 0.f, mean_ = 0.f, m2_ = 0.f;
+            for (int base = 0; base < p.fslots; base += TPR * 8) {
+                float2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int sl = base + i * TPR + sub;
+                    v[i] = st[(size_t)(sl < p.fslots ? sl : p.fslots - 1) * p.fstride];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (base + i * TPR + sub < p.fslots) {
+                        const float nn = n_ + w, d = v[i].x * invw - mean_, inv = __builtin_amdgcn_rcpf(nn);
+                        mean_ += d * (w * inv);
+                        m2_ += v[i].y + (d * d) * (n_ * w * inv);
+                        n_ = nn;
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) {
+                const float nb = __shfl_xor(n_, o), mb = __shfl_xor(mean_, o), qb = __shfl_xor(m2_, o);
+                const bool upper = (sub & o) != 0;
+                const float n0_ = upper ? nb : n_, m0_ = upper ? mb : mean_, q0_ = upper ? qb : m2_;      // the lower lane's aggregate first
+                const float n1_ = upper ? n_ : nb, m1_ = upper ? mean_ : mb, q1_ = upper ? m2_ : qb;
+                const float nn = n0_ + n1_, d = m1_ - m0_, inv = __builtin_amdgcn_rcpf(nn > 0.f ? nn : 1.f);
+                mean_ = m0_ + d * (n1_ * inv);
+                m2_ = q0_ + q1_ + (d * d) * (n0_ * n1_ * inv);
+                n_ = nn;
+            }
+            if (sub == 0) lnst[r] = make_float2(mean_, 1.0f / sqrtf(m2_ / n_ + p.eps));
+        }
+    }
     SK_STAMP(2);           // LayerNorm prologue done (statistics round trip + barrier)
     f4 acc[MF];
 #pragma unroll
@@ -213,6 +261,12 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         const int n = n0 + fgrp * 4;
         const int m = m_base + b * 16 + frow;
         const bool ok = m < p.M && n < p.W.N;
+        if constexpr (FOLDC) {
+            if (foldc) {               // rstd (acc - mean c): (mean, rstd) of this lane's row, written before the barrier above
+                const float2 st = lnst[b * 16 + frow];
+                v = (v - c_pre * st.x) * st.y;
+            }
+        }
         v = v + (b == wave ? bias_pre : (f4){0.f, 0.f, 0.f, 0.f});   // (MF <= NW: a wave finalises at most the one fragment row b == wave)
         if constexpr (EPI == EPI_F32) {
             if (ok) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
@@ -222,6 +276,18 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
                 const f4 r = resid_pre;
                 o = r + v;
                 *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = o;
+            }
+            if (p.xg_out) {      // LayerNorm fold, producer half: the next GEMM's operand fp16(x gamma_next) and the statistics of this
+                                 // workgroup's 16 columns (sum, sum of squared deviations from their mean: two passes in registers)
+                if (ok) {
+                    const f4 g = o * gam_pre;
+                    const h2 glo = (h2){(_Float16)g[0], (_Float16)g[1]}, ghi = (h2){(_Float16)g[2], (_Float16)g[3]};
+                    *(uint2 *)(p.xg_out + (size_t)m * p.ldxg + n) = make_uint2(h2u(glo), h2u(ghi));
+                }
+                const float s = sum4_fgrp((o[0] + o[1]) + (o[2] + o[3]));
+                const f4 dd = o - s * (1.0f / 16.0f);
+                const float q = sum4_fgrp((dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]));
+                if (fgrp == 0 && m < p.M) p.fstats_out[(size_t)blockIdx.x * p.fstride_out + m] = make_float2(s, q);
             }
             if (p.stats_out) {   // partial LayerNorm statistics of the NEW residual row over this workgroup's 16 columns
                 float s1 = (o[0] + o[1]) + (o[2] + o[3]);
@@ -283,6 +349,9 @@ void launch_sk_epi(const SkinnyParams & p, int epi, hipStream_t stream) {
     }
     switch (epi) {
     case EPI_F32: launch_sk<WT, MF, 4, EPI_F32, false>(p, stream); break;
+    case EPI_F16: launch_sk<WT, MF, 4, EPI_F16, false>(p, stream); break;               // fp16 A + fp16 epilogues: the consumers of the LayerNorm fold
+    case EPI_GELU_F16: launch_sk<WT, MF, 4, EPI_GELU_F16, false>(p, stream); break;
+    case EPI_QGELU_F16: launch_sk<WT, MF, 4, EPI_QGELU_F16, false>(p, stream); break;
     case EPI_RESID_F32:
         if (long_k) launch_sk<WT, MF, 8, EPI_RESID_F32, false>(p, stream);
         else launch_sk<WT, MF, 4, EPI_RESID_F32, false>(p, stream);
@@ -323,6 +392,8 @@ bool skinny_supported(const SkinnyParams & p, int epilogue) {
         return p.W.K == p.W.Kpad && p.W.K <= 2048 && p.ldx % 4 == 0 && p.ln_w && p.ln_b && p.stats_in && p.stats_slots > 0;
     }
     if (epilogue == EPI_PATCH_F32) return p.W.wtype == W_F16 && p.lda % 8 == 0;
+    if (epilogue == EPI_F16 || epilogue == EPI_GELU_F16 || epilogue == EPI_QGELU_F16)      // fold consumer: statistics + c vector required
+        return p.lda % 8 == 0 && p.ln_c && p.fstats && p.fslots > 0 && p.fslotw > 0 && p.M <= 128;
     return (epilogue == EPI_F32 || epilogue == EPI_RESID_F32) && p.lda % 8 == 0;
 }
 

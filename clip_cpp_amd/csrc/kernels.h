@@ -163,6 +163,19 @@ struct SkinnyParams {
     const float * pos = nullptr;
     float2 * stats_out = nullptr;        // EPI_RESID_F32: [row][stats_cap], entry blockIdx.x = statistics of the row over this workgroup's 16 columns
     int stats_cap = 128;
+    // LayerNorm fold on the small-M path (same algebra as GemmParams::ln_* / xg_*; gemm_common.h).  Consumer (fp16 epilogues with
+    // ln_c != null): A16 holds fp16(x gamma), bias holds b', the epilogue applies rstd (acc - mean c) + b'; the row statistics are
+    // reduced in the kernel's prologue from fstats [fslots][fstride] (slots of fslotw columns: 16 out of the skinny residual epilogue,
+    // or ONE slot of width h out of the entry kernel).  Producer (EPI_RESID_F32 with xg_out != null): also writes xg_out = fp16(out gamma_next)
+    // and fstats_out[blockIdx.x][row] = (sum, sum of squared deviations) of the row over this workgroup's 16 columns.
+    const float * ln_c = nullptr;
+    const float2 * fstats = nullptr;
+    int fslots = 0, fslotw = 0, fstride = 0;
+    half_t * xg_out = nullptr;
+    int ldxg = 0;
+    const float * xg_gamma = nullptr;
+    float2 * fstats_out = nullptr;
+    int fstride_out = 0;
     unsigned long long * stamps = nullptr;   // -DCLIPAMD_SK_TIMING builds (scripts/build_sk_timing.sh): 16 phase stamps of the first and the last workgroup
 };
 constexpr int SKINNY_MAX_ROWS = 512;    // rows the statistics buffers are sized for ([2][SKINNY_MAX_ROWS][stats_cap] float2)

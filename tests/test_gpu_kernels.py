@@ -652,3 +652,28 @@ def test_large_m_kernels_vs_float64_at_model_size(L, tname, M, N, K):
         resid = rng.standard_normal((M, N)).astype(np.float32)
         yr = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=4)
         assert np.array_equal(yr, resid + ys[0]) or np.max(np.abs(yr - (resid + ys[0]))) <= 1e-6 * np.max(np.abs(resid))
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "f16", "q5_1", "q8_0"])
+@pytest.mark.parametrize("M,h,K1,N2,epi2", [(50, 768, 768, 2304, 1), (50, 768, 3072, 3072, 3), (13, 512, 2048, 2048, 2), (64, 1024, 1024, 3072, 1), (1, 1280, 1280, 5120, 2), (77, 512, 512, 1536, 1)])
+def test_lnfold_small_m_kernels(L, tname, M, h, K1, N2, epi2):
+    """The folded LayerNorm on the small-M path (one image, one text): skinny residual epilogue -> fp16(x gamma) + 16-column statistics ->
+    skinny consumer.  Rigorous bound against float64, agreement with the LayerNorm-fused-on-the-operand form of the same kernels, and
+    the f32 residual rows bit-identical between the two forms."""
+    rng = np.random.default_rng(M * 3 + h + epi2)
+    tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2)
+    qc, qs = (h, 0.125) if epi2 == 1 else (0, 1.0)
+    x1a, ya = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, -1, 0, 0, qc, qs)
+    x1b, yb = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, -1, 0, 1, qc, qs)
+    assert np.array_equal(x1a, x1b), _diff_report(x1a, x1b)
+    want, bound, lin = _lnfold_reference(x1b, g, beta, Wd2, b2, epi2, qc, qs)
+    err = np.abs(yb - want)
+    bad = np.argwhere(err > bound)
+    assert np.all(np.isfinite(yb)) and bad.size == 0, "%d/%d bad, max err %g" % (len(bad), yb.size, err.max())
+    scale = np.maximum(np.abs(ya), np.sqrt((ya.astype(np.float64) ** 2).mean(1, keepdims=True)))
+    ab = np.abs(yb - ya) / (scale * 2.0 ** -10)
+    assert ab.max() <= 3.0 and np.quantile(ab, 0.999) <= 2.0, "A/B max %.2f ulp, p99.9 %.2f" % (ab.max(), np.quantile(ab, 0.999))
+    # and against the tiled kernels' fold on the same inputs: same operand fp16(x gamma), statistics from other partial sums
+    x1c, yc = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, 64128, 64128, 1, qc, qs)
+    ab2 = np.abs(yb - yc) / (scale * 2.0 ** -10)
+    assert ab2.max() <= 2.0, ab2.max()
