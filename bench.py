@@ -78,6 +78,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the text tower behind the vision tower on ONE stream (default: two contexts on two HIP streams, so "
                          "the small text kernels fill the tails of the vision kernels)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="SURVEY 8(e) form: ONE process, clip_amd_model_load_multi (a replica context + stream + host thread per GPU), "
+                         "device-resident shards, ONE grouped ncclAllGather per tower — run as `python bench.py --gpus N --single-process` "
+                         "(no torch.distributed.run); the default N > 1 form is one torch process per GPU")
     ap.add_argument("--no-matrix", action="store_true", help="default config only: skip the other cells of the north_star matrix")
     ap.add_argument("--matrix", action="store_true", help="run the matrix cells also with a non-default --config")
     ap.add_argument("--json-out", default=None)
@@ -201,6 +205,82 @@ MATRIX_L14 = ["l14_f16_b1", "l14_f16_b32", "l14_f16_b256"]
 L14_GEN_GUARD_S = 60.0
 
 
+def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, synth):
+    """The C-ABI multi-GPU path on the measured path: one process, N replicas behind clip_amd_model_load_multi, shard g of
+    every batch resident on device g, the towers of a step back to back on each replica's stream, one grouped ncclAllGather (RCCL over
+    xGMI) of the embeddings per tower call.  Weak scaling: `batch` images + `n_texts` texts per GPU per step.  The calls are synchronous
+    (they return when every replica stream has finished), so the timed region needs no further barrier."""
+    N = args.gpus
+    if clip_cpp_amd.device_count() < N:
+        raise SystemExit("bench.py --single-process --gpus %d: only %d HIP devices visible" % (N, clip_cpp_amd.device_count()))
+    cache = os.environ.get("CLIP_AMD_FIXTURE_CACHE", "/tmp/clip_amd_fixtures")
+    path = synth.cached_model(cache, cfg["model"], cfg["ftype"], text=n_texts > 0, vision=True, seed=1234)
+    if N == 1:
+        os.environ.setdefault("CLIP_AMD_MULTI_FORCE_RCCL", "1")       # one replica still goes through ncclCommInitAll + the grouped all-gather
+    clip = clip_cpp_amd.Clip(path, verbosity=0, n_devices=N)
+    vc, tc = clip.vision_config, clip.text_config
+    if n_texts == 0:
+        tc = dict(tc, num_positions=77)
+    S, proj = vc["image_size"], vc["projection_dim"]
+    imgs, ids, img_ptrs, id_ptrs, all_texts = [], [], [], [], []
+    for g in range(N):
+        gen = torch.Generator(device="cuda:%d" % g)
+        gen.manual_seed(1000 + g)
+        t = torch.randn((batch, S, S, 3), dtype=torch.float32, device="cuda:%d" % g, generator=gen)
+        imgs.append(t)
+        img_ptrs.append(t.data_ptr())
+        texts = synth.token_ids(n_texts, seed=11 + g, min_len=1, max_len=min(75, tc["num_positions"] - 2))
+        all_texts += texts
+        flat = np.concatenate(texts).astype(np.int32) if n_texts else np.zeros(1, np.int32)
+        ti = torch.from_numpy(flat).to("cuda:%d" % g)
+        ids.append(ti)
+        id_ptrs.append(ti.data_ptr())
+    offsets = np.concatenate([[0], np.cumsum([len(t) for t in all_texts])]).astype(np.int32)
+    for g in range(N):
+        torch.cuda.synchronize(g)
+
+    def step():
+        clip.encode_images_device_multi(img_ptrs, N * batch, True)
+        if n_texts:
+            clip.encode_texts_device_multi(id_ptrs, offsets, True)
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.preheat:
+        step()
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    out_i = np.empty((N * batch, proj), dtype=np.float32)
+    clip.encode_images_device_multi(img_ptrs, N * batch, True, out_i)
+    assert np.all(np.isfinite(out_i)), "non-finite embeddings"
+    fl_step, by_step = algorithmic_work(vc, tc, cfg["ftype"], batch, [len(t) for t in all_texts[:n_texts]])
+    ms_step = dt / steps * 1e3
+    t_mfma_ws, t_hbm_ws = fl_step / (MFMA_F16_PEAK_TFLOPS * 1e12), by_step / (HBM_PEAK_GBS * 1e9)
+    out = {"metric": "image+text embeddings/sec", "value": round(N * (batch + n_texts) * steps / dt, 1), "unit": "embeddings/s", "n_gpus": N,
+           "steps": steps, "warmup": args.warmup, "preheat_s": args.preheat, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "CLIP ViT-%s %s: %d images%s per GPU per step, shards resident in HBM, ONE process with a replica context + stream + "
+                                  "host thread per GPU (clip_amd_model_load_multi), towers back to back on each replica's stream, one grouped "
+                                  "ncclAllGather of the final embeddings per tower call" % (cfg["model"].upper(), cfg["ftype"], batch,
+                                                                                           (" + %d texts" % n_texts) if n_texts else ""),
+                      "name": args.config, "images_per_gpu": batch, "texts_per_gpu": n_texts, "parallelism": "dp%d single-process" % N},
+           "whole_step_roofline": {"bound": "mfma" if t_mfma_ws >= t_hbm_ws else "hbm", "algorithmic_flops_per_step": fl_step,
+                                   "algorithmic_bytes_per_step": by_step, "frac": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4),
+                                   "note": "per GPU"},
+           "roofline": None, "cpu_baseline": None,
+           "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)"}
+    line = json.dumps(out)
+    print(line, flush=True)
+    if args.json_out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
+        with open(args.json_out, "w") as f:
+            f.write(line + "\n")
+    clip.close()
+
+
 def main():
     args = parse()
     import torch
@@ -221,6 +301,8 @@ def main():
     vision_only = n_texts == 0
     custom = bool(args.model or args.ftype or args.batch > 0 or args.texts >= 0 or args.vision_only)
 
+    if args.single_process:
+        return single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, synth)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

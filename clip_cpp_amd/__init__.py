@@ -152,6 +152,10 @@ def lib():
     L.clip_amd_image_batch_encode_u8.argtypes = [vp, C.POINTER(ClipImageU8), i32, f32p, C.c_bool]
     L.clip_amd_text_batch_encode_device.restype = C.c_bool
     L.clip_amd_text_batch_encode_device.argtypes = [vp, vp, C.POINTER(C.c_int32), i32, vp, C.c_bool]
+    L.clip_amd_image_batch_encode_device_multi.restype = C.c_bool
+    L.clip_amd_image_batch_encode_device_multi.argtypes = [vp, C.POINTER(vp), i32, C.c_bool, f32p]
+    L.clip_amd_text_batch_encode_device_multi.restype = C.c_bool
+    L.clip_amd_text_batch_encode_device_multi.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, C.c_bool, f32p]
     L.clip_amd_profile_enable.argtypes = [vp, C.c_bool]
     L.clip_amd_profile_report.restype = i32
     L.clip_amd_profile_report.argtypes = [vp, C.c_char_p, i32, C.c_bool]
@@ -389,6 +393,25 @@ class Clip:
         if not lib().clip_amd_text_batch_encode_device(self.ctx, C.c_void_p(d_ids_ptr), off.ctypes.data_as(C.POINTER(C.c_int32)),
                                                        off.size - 1, C.c_void_p(d_out_ptr), normalize):
             raise RuntimeError("clip_amd_text_batch_encode_device failed (see stderr)")
+
+    def encode_images_device_multi(self, d_img_ptrs, total, normalize=True, out=None):
+        """Multi-GPU handle (n_devices=...): shard g of `total` preprocessed images already on device g at d_img_ptrs[g] (ints); one
+        RCCL all-gather of the embeddings; returns the host copy [total, proj] when out is given (np.float32 array), else None."""
+        arr = (C.c_void_p * len(d_img_ptrs))(*[C.c_void_p(p) for p in d_img_ptrs])
+        if not lib().clip_amd_image_batch_encode_device_multi(self.ctx, arr, total, normalize, _fp(out) if out is not None else None):
+            raise RuntimeError("clip_amd_image_batch_encode_device_multi failed (see stderr)")
+        return out
+
+    def encode_texts_device_multi(self, d_ids_ptrs, offsets, normalize=True, out=None):
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        arr = (C.c_void_p * len(d_ids_ptrs))(*[C.c_void_p(p) for p in d_ids_ptrs])
+        if not lib().clip_amd_text_batch_encode_device_multi(self.ctx, arr, off.ctypes.data_as(C.POINTER(C.c_int32)), off.size - 1, normalize,
+                                                             _fp(out) if out is not None else None):
+            raise RuntimeError("clip_amd_text_batch_encode_device_multi failed (see stderr)")
+        return out
+
+    def gathered_embeddings_ptr(self, device_index=0):
+        return lib().clip_amd_gathered_embeddings(self.ctx, device_index)
 
     def profile(self, on=True):
         lib().clip_amd_profile_enable(self.ctx, on)

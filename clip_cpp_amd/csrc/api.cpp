@@ -217,6 +217,33 @@ bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct 
 // raw u8 images -> embeddings with the resize/crop/normalise on the GPU (bit-identical to clip_image_preprocess):
 // ships <= 3 B/pixel of the ORIGINAL image instead of 12 B/pixel of the resized one and takes the double-precision
 // resampling (the dominant host cost of benchmark.cpp / zsl.cpp style callers) off the CPU.
+// n raw images -> d_out [n][proj] on ctx's device, queued on ctx->stream (chunks of <= 256 images / ~512 MB of raw pixels; the host
+// side of a chunk's staging is re-used by the next one, hence the synchronisation between chunks).
+static bool encode_u8_to_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out, bool normalize) {
+    const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
+    const size_t per = (size_t)S * S * 3;
+    (void)hipSetDevice(ctx->device);
+    bool ok = true;
+    int b0 = 0;
+    while (b0 < n && ok) {
+        int bc = 0;
+        size_t bytes = 0;
+        while (b0 + bc < n && bc < 256 && (bc == 0 || bytes < ((size_t)512 << 20))) {
+            bytes += (size_t)3 * (size_t)std::max(0, imgs[b0 + bc].nx) * (size_t)std::max(0, imgs[b0 + bc].ny);
+            bc++;
+        }
+        if (!ensure_io(ctx, per * 4 * std::min(n, 256), 16)) {
+            fprintf(stderr, "clip_amd_image_batch_encode_u8: out of device memory\n");
+            return false;
+        }
+        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in);
+        ok = ok && vision_forward_device(ctx, (const float *)ctx->io_in, bc, d_out + (size_t)b0 * proj, normalize);
+        b0 += bc;
+        if (b0 < n) ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    return ok;
+}
+
 bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * vec, bool normalize) try {
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
@@ -227,33 +254,71 @@ bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_ima
         return false;
     }
     if (n <= 0) return true;
-    const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
-    const size_t per = (size_t)S * S * 3;
-    (void)hipSetDevice(ctx->device);
-    bool ok = true;
-    int b0 = 0;
-    while (b0 < n && ok) {
-        // chunk: at most 256 images and ~512 MB of raw pixels
-        int bc = 0;
-        size_t bytes = 0;
-        while (b0 + bc < n && bc < 256 && (bc == 0 || bytes < ((size_t)512 << 20))) {
-            bytes += (size_t)3 * (size_t)std::max(0, imgs[b0 + bc].nx) * (size_t)std::max(0, imgs[b0 + bc].ny);
-            bc++;
-        }
-        if (!ensure_io(ctx, per * 4 * std::min(n, 256), (size_t)proj * 4 * std::min(n, 256))) {
-            fprintf(stderr, "clip_amd_image_batch_encode_u8: out of device memory\n");
-            return false;
-        }
-        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in);
-        ok = ok && vision_forward_device(ctx, (const float *)ctx->io_in, bc, (float *)ctx->io_out, normalize);
-        ok = ok && hipMemcpyAsync(vec + (size_t)b0 * proj, ctx->io_out, (size_t)proj * 4 * bc, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    const int proj = ctx->vision_hparams.projection_dim;
+    bool ok;
+    if (ctx->multi && n >= 2 * multi_device_count(ctx)) {
+        // sharded over the devices of a clip_amd_model_load_multi context (the ~150 KB / image entry point is the one
+        // that can scale; the f32 host path is PCIe- and packer-bound on one GPU already): each replica preprocesses and encodes its own
+        // contiguous shard, ONE all-gather of the embeddings
+        ok = multi_run(ctx, n, proj, vec, "clip_amd_image_batch_encode_u8",
+                       [&](int, clip_ctx * c, int l, int h, float * d_send) { return encode_u8_to_device(c, imgs + l, h - l, d_send, normalize); });
+    } else {
+        (void)hipSetDevice(ctx->device);
+        ok = ensure_io(ctx, 16, (size_t)proj * 4 * n);
+        ok = ok && encode_u8_to_device(ctx, imgs, n, (float *)ctx->io_out, normalize);
+        ok = ok && hipMemcpyAsync(vec, ctx->io_out, (size_t)proj * 4 * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
         ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
-        b0 += bc;
     }
     if (!ok) fprintf(stderr, "clip_amd_image_batch_encode_u8: failed (%s)\n", hipGetErrorString(hipGetLastError()));
     if (ctx->profiling) prof_collect(ctx);
     return ok;
 } catch (const std::exception & e) { fprintf(stderr, "clip_amd_image_batch_encode_u8: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_amd_image_batch_encode_u8: unknown exception\n"); return false; }
+
+// Device-resident sharded image encode on a clip_amd_model_load_multi context (the measured form of SURVEY 8e: bench.py --single-process).
+// d_imgs[g]: the preprocessed f32 images of shard g ([hi - lo][S][S][3], clip_amd_shard_bounds(total, G, g)) ON device g.
+bool clip_amd_image_batch_encode_device_multi(struct clip_ctx * ctx, const float * const * d_imgs, int total, bool normalize, float * vec) try {
+    if (!ctx || !ctx->multi || !ctx->has_vision_encoder || !d_imgs) { fprintf(stderr, "clip_amd_image_batch_encode_device_multi: needs a clip_amd_model_load_multi context with a vision encoder\n"); return false; }
+    if (total <= 0) return true;
+    return multi_run(ctx, total, ctx->vision_hparams.projection_dim, vec, "clip_amd_image_batch_encode_device_multi",
+                     [&](int g, clip_ctx * c, int l, int h, float * d_send) { return vision_forward_device(c, d_imgs[g], h - l, d_send, normalize); });
+} catch (...) { fprintf(stderr, "clip_amd_image_batch_encode_device_multi: exception\n"); return false; }
+
+// ... and of ragged texts: d_ids[g] = the ids of shard g's texts back to back ON device g, h_offsets = total + 1 prefix offsets of ALL texts (host).
+bool clip_amd_text_batch_encode_device_multi(struct clip_ctx * ctx, const int32_t * const * d_ids, const int32_t * h_offsets, int total, bool normalize,
+                                             float * vec) try {
+    if (!ctx || !ctx->multi || !ctx->has_text_encoder || !d_ids || !h_offsets) { fprintf(stderr, "clip_amd_text_batch_encode_device_multi: needs a clip_amd_model_load_multi context with a text encoder\n"); return false; }
+    if (total <= 0) return true;
+    const int G = multi_device_count(ctx);
+    std::vector<std::vector<int32_t>> off(G);          // per-shard offsets rebased to 0 (kept alive until multi_run has synchronised)
+    return multi_run(ctx, total, ctx->text_hparams.projection_dim, vec, "clip_amd_text_batch_encode_device_multi",
+                     [&](int g, clip_ctx * c, int l, int h, float * d_send) {
+                         off[g].resize((size_t)(h - l) + 1);
+                         for (int i = l; i <= h; i++) off[g][(size_t)(i - l)] = h_offsets[i] - h_offsets[l];
+                         return text_forward_device(c, d_ids[g], off[g].data(), h - l, d_send, normalize);
+                     });
+} catch (...) { fprintf(stderr, "clip_amd_text_batch_encode_device_multi: exception\n"); return false; }
+
+// n ragged texts (host token lists) -> d_out [n][proj] on ctx's device, queued on ctx->stream.  ids / off: caller-owned staging that must
+// stay alive until the stream is synchronised (the upload of pageable memory may still be reading it).
+static bool texts_to_device(clip_ctx * ctx, const clip_tokens * tokens, size_t n_texts, std::vector<int32_t> & ids, std::vector<int32_t> & off,
+                            float * d_out, bool normalize) {
+    ids.clear();
+    off.assign(n_texts + 1, 0);
+    for (size_t i = 0; i < n_texts; i++) {
+        if (!tokens[i].data || tokens[i].size == 0) { fprintf(stderr, "clip_text_encode: empty token list\n"); return false; }
+        for (size_t j = 0; j < tokens[i].size; j++) {
+            const int32_t id = tokens[i].data[j];
+            if (id < 0 || id >= ctx->text_hparams.n_vocab) { fprintf(stderr, "clip_text_encode: token id %d out of range\n", id); return false; }
+            ids.push_back(id);
+        }
+        off[i + 1] = (int32_t)ids.size();
+    }
+    (void)hipSetDevice(ctx->device);
+    // persistent device staging (ids in io_in): no hipMalloc / hipFree on the per-call path
+    if (!ensure_io(ctx, ids.size() * 4, 16)) { fprintf(stderr, "clip_text_encode: out of device memory\n"); return false; }
+    bool ok = hipMemcpyAsync(ctx->io_in, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    return ok && text_forward_device(ctx, (const int32_t *)ctx->io_in, off.data(), (int)n_texts, d_out, normalize);
+}
 
 bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_tokens * tokens, size_t n_texts, float * vec,
                             const bool normalize) try {
@@ -268,24 +333,22 @@ bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, c
         return false;
     }
     if (n_texts == 0) return true;
-    std::vector<int32_t> ids, off(n_texts + 1, 0);
-    for (size_t i = 0; i < n_texts; i++) {
-        if (!tokens[i].data || tokens[i].size == 0) { fprintf(stderr, "clip_text_encode: empty token list\n"); return false; }
-        for (size_t j = 0; j < tokens[i].size; j++) {
-            const int32_t id = tokens[i].data[j];
-            if (id < 0 || id >= ctx->text_hparams.n_vocab) { fprintf(stderr, "clip_text_encode: token id %d out of range\n", id); return false; }
-            ids.push_back(id);
-        }
-        off[i + 1] = (int32_t)ids.size();
-    }
-    (void)hipSetDevice(ctx->device);
     const int proj = ctx->text_hparams.projection_dim;
-    // persistent device staging (ids in io_in, embeddings in io_out): no hipMalloc / hipFree on the per-call path
-    if (!ensure_io(ctx, ids.size() * 4, n_texts * (size_t)proj * 4)) { fprintf(stderr, "clip_text_encode: out of device memory\n"); return false; }
-    bool ok = hipMemcpyAsync(ctx->io_in, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-    ok = ok && text_forward_device(ctx, (const int32_t *)ctx->io_in, off.data(), (int)n_texts, (float *)ctx->io_out, normalize);
-    ok = ok && hipMemcpyAsync(vec, ctx->io_out, n_texts * (size_t)proj * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-    ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    bool ok;
+    if (ctx->multi && n_texts >= 2 * (size_t)multi_device_count(ctx)) {
+        // sharded over the devices of a clip_amd_model_load_multi context: contiguous runs of texts per replica, ONE all-gather
+        const int G = multi_device_count(ctx);
+        std::vector<std::vector<int32_t>> ids(G), off(G);
+        ok = multi_run(ctx, (int)n_texts, proj, vec, "clip_text_batch_encode",
+                       [&](int g, clip_ctx * c, int l, int h, float * d_send) { return texts_to_device(c, tokens + l, (size_t)(h - l), ids[g], off[g], d_send, normalize); });
+    } else {
+        std::vector<int32_t> ids, off;
+        (void)hipSetDevice(ctx->device);
+        ok = ensure_io(ctx, 16, n_texts * (size_t)proj * 4);
+        ok = ok && texts_to_device(ctx, tokens, n_texts, ids, off, (float *)ctx->io_out, normalize);
+        ok = ok && hipMemcpyAsync(vec, ctx->io_out, n_texts * (size_t)proj * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
     if (ctx->profiling) prof_collect(ctx);
     return ok;
 } catch (const std::exception & e) { fprintf(stderr, "clip_text_batch_encode: %s\n", e.what()); return false; } catch (...) { fprintf(stderr, "clip_text_batch_encode: unknown exception\n"); return false; }

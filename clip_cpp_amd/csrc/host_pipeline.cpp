@@ -355,6 +355,7 @@ struct MultiCtx {
     Rccl rccl;
     bool use_rccl = true;
     bool collective = false;              // the all-gather runs (G > 1, or G == 1 with CLIP_AMD_MULTI_FORCE_RCCL=1)
+    PackPool replicas;                    // one persistent host thread per replica beyond the first (the caller drives replica 0)
 };
 
 clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
@@ -371,15 +372,21 @@ clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
     }
     MultiCtx * mc = new MultiCtx();
     mc->G = n_devices;
-    for (int g = 0; g < n_devices; g++) {
-        clip_ctx * c = load_model(fname, g == 0 ? verbosity : 0, g % ndev);
-        if (!c) {
-            for (clip_ctx * r : mc->rep) free_model(r);
+    // the replicas load concurrently (G sequential parses + repacks, ~2 s each for ViT-L/14): the GGUF is mapped read-only
+    // by every loader, each thread binds its own device
+    mc->rep.assign(n_devices, nullptr);
+    {
+        std::vector<std::thread> loaders;
+        for (int g = 1; g < n_devices; g++) loaders.emplace_back([&, g] { mc->rep[g] = load_model(fname, 0, g % ndev); });
+        mc->rep[0] = load_model(fname, verbosity, 0);
+        for (auto & t : loaders) t.join();
+    }
+    for (int g = 0; g < n_devices; g++)
+        if (!mc->rep[g]) {
+            for (clip_ctx * r : mc->rep) if (r) free_model(r);
             delete mc;
             return nullptr;
         }
-        mc->rep.push_back(c);
-    }
     mc->send.assign(n_devices, nullptr); mc->recv.assign(n_devices, nullptr);
     mc->send_floats.assign(n_devices, 0); mc->recv_floats.assign(n_devices, 0);
     // CLIP_AMD_MULTI_FORCE_RCCL=1 (test aid for 1-GPU machines): a single replica still goes through ncclCommInitAll and a one-rank
@@ -423,14 +430,19 @@ void multi_free(clip_ctx * primary) {
 
 int multi_device_count(const clip_ctx * primary) { return primary && primary->multi ? ((MultiCtx *)primary->multi)->G : 1; }
 
-// B images sharded over the G devices of a multi context; vec [B][proj] on the host.
-bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, int B, float * vec, bool normalize, int n_threads) {
+// The sharded form of a batch call on a multi context: `total` items in contiguous shards of ceil(total / G), shard g on
+// replica g — run(g, ctx_g, lo, hi, d_send) queues everything that turns items [lo, hi) into [hi - lo][proj] f32 rows at d_send on
+// ctx_g's stream — short shards padded with zero rows, then ONE grouped ncclAllGather (RCCL over xGMI) of [per_dev][proj] into
+// [G * per_dev][proj] on every device (clip_amd_gathered_embeddings) and, when vec != nullptr, one device-to-host copy of the first
+// `total` rows from device 0.  Replica g > 0 is driven by its persistent host thread (std::thread per call before).
+// Returns with every replica stream synchronised.
+bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char * who,
+               const std::function<bool(int, clip_ctx *, int, int, float *)> & run) {
     MultiCtx * mc = (MultiCtx *)primary->multi;
-    const int G = mc->G, proj = primary->vision_hparams.projection_dim;
+    const int G = mc->G;
     int per_dev = 0, lo = 0, hi = 0;
-    multi_shard(B, G, 0, &lo, &hi, &per_dev);
+    multi_shard(total, G, 0, &lo, &hi, &per_dev);
     std::vector<char> okv(G, 1);
-    const int thr = std::max(1, n_threads / G);
     auto work = [&](int g) {
         clip_ctx * c = mc->rep[g];
         (void)hipSetDevice(c->device);
@@ -441,17 +453,12 @@ bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, i
         if (!grow_device(sp, sb, (size_t)per_dev * proj * 4) || !grow_device(rp, rb, (size_t)G * per_dev * proj * 4)) { okv[g] = 0; return; }
         mc->send[g] = (float *)sp; mc->recv[g] = (float *)rp; mc->send_floats[g] = sb / 4; mc->recv_floats[g] = rb / 4;
         int l, h, pd;
-        multi_shard(B, G, g, &l, &h, &pd);
+        multi_shard(total, G, g, &l, &h, &pd);
         if (h - l < per_dev) (void)hipMemsetAsync(mc->send[g] + (size_t)(h - l) * proj, 0, (size_t)(per_dev - (h - l)) * proj * 4, c->stream);   // padding rows of a short shard
-        if (h > l && !encode_images_from_host(c, imgs + l, h - l, mc->send[g], normalize, thr)) okv[g] = 0;
+        if (h > l && !run(g, c, l, h, mc->send[g])) okv[g] = 0;
     };
-    {
-        std::vector<std::thread> pool;
-        for (int g = 1; g < G; g++) pool.emplace_back(work, g);
-        work(0);
-        for (auto & th : pool) th.join();
-    }
-    for (int g = 0; g < G; g++) if (!okv[g]) { fprintf(stderr, "clip_image_batch_encode: shard %d failed\n", g); return false; }
+    mc->replicas.run(G, work);
+    for (int g = 0; g < G; g++) if (!okv[g]) { fprintf(stderr, "%s: shard %d failed\n", who, g); return false; }
     bool ok = true;
     if (mc->collective && mc->use_rccl) {
         // ONE all-gather of the final embeddings: [per_dev][proj] per device -> [G * per_dev][proj] on every device
@@ -459,18 +466,18 @@ bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, i
         for (int g = 0; g < G && ok; g++)
             ok = mc->rccl.AllGather(mc->send[g], mc->recv[g], (size_t)per_dev * proj, kNcclFloat, mc->comms[g], mc->rep[g]->stream) == 0;
         ok = (mc->rccl.GroupEnd() == 0) && ok;
-        if (!ok) { fprintf(stderr, "clip_image_batch_encode: ncclAllGather failed\n"); return false; }
+        if (!ok) { fprintf(stderr, "%s: ncclAllGather failed\n", who); return false; }
         (void)hipSetDevice(primary->device);
-        // shards are contiguous and only the LAST non-empty one can be short, so the first B rows of the gathered buffer are the result
-        ok = hipMemcpyAsync(vec, mc->recv[0], (size_t)B * proj * 4, hipMemcpyDeviceToHost, primary->stream) == hipSuccess;
+        // shards are contiguous and only the LAST non-empty one can be short, so the first `total` rows of the gathered buffer are the result
+        if (vec) ok = hipMemcpyAsync(vec, mc->recv[0], (size_t)total * proj * 4, hipMemcpyDeviceToHost, primary->stream) == hipSuccess;
         for (int g = 0; g < G; g++) {
             (void)hipSetDevice(mc->rep[g]->device);
             ok = hipStreamSynchronize(mc->rep[g]->stream) == hipSuccess && ok;
         }
     } else {
-        for (int g = 0; g < G; g++) {
+        for (int g = 0; g < G && vec; g++) {
             int l, h, pd;
-            multi_shard(B, G, g, &l, &h, &pd);
+            multi_shard(total, G, g, &l, &h, &pd);
             (void)hipSetDevice(mc->rep[g]->device);
             if (h > l) ok = hipMemcpyAsync(vec + (size_t)l * proj, mc->send[g], (size_t)(h - l) * proj * 4, hipMemcpyDeviceToHost, mc->rep[g]->stream) == hipSuccess && ok;
         }
@@ -481,6 +488,18 @@ bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, i
     }
     (void)hipSetDevice(primary->device);
     return ok;
+}
+
+// B preprocessed images (host) sharded over the G devices of a multi context; vec [B][proj] on the host.
+bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, int B, float * vec, bool normalize, int n_threads) {
+    const int thr = std::max(1, n_threads / multi_device_count(primary));
+    return multi_run(primary, B, primary->vision_hparams.projection_dim, vec, "clip_image_batch_encode",
+                     [&](int, clip_ctx * c, int l, int h, float * d_send) { return encode_images_from_host(c, imgs + l, h - l, d_send, normalize, thr); });
+}
+
+clip_ctx * multi_replica(const clip_ctx * primary, int g) {
+    const MultiCtx * mc = (const MultiCtx *)primary->multi;
+    return mc && g >= 0 && g < mc->G ? mc->rep[g] : nullptr;
 }
 
 // device-resident gathered result of the last multi encode on device g (tests / callers that keep the embeddings on the GPUs)

@@ -7,6 +7,7 @@
 // reference :261-331 are replaced by a workspace sized from hparams x batch.
 #pragma once
 
+#include <functional>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -177,6 +178,10 @@ clip_ctx * multi_load(const char * fname, int verbosity, int n_devices);
 void multi_free(clip_ctx * primary);
 int multi_device_count(const clip_ctx * primary);
 bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, int B, float * vec, bool normalize, int n_threads);
+// generic sharded call: run(g, ctx_g, lo, hi, d_send) queues the work of items [lo, hi) on replica g; see host_pipeline.cpp
+bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char * who,
+               const std::function<bool(int, clip_ctx *, int, int, float *)> & run);
+clip_ctx * multi_replica(const clip_ctx * primary, int g);
 const float * multi_gathered(const clip_ctx * primary, int g);
 
 // host pieces

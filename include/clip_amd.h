@@ -46,6 +46,17 @@ void clip_amd_shard_bounds(int total, int n_devices, int device_index, int * lo,
  * the last sharded clip_image_batch_encode: the canonical device-resident result (valid until the next call). */
 const float * clip_amd_gathered_embeddings(const struct clip_ctx * ctx, int device_index);
 
+/* Device-resident sharded encodes on a clip_amd_model_load_multi handle (the form bench.py --single-process measures): shard g of the
+ * batch — items [lo, hi) of clip_amd_shard_bounds(total, n_devices, g) — already sits ON device g: d_imgs[g] = [hi - lo][S][S][3] f32
+ * preprocessed images; d_ids[g] = the token ids of the shard's texts back to back, h_offsets = total + 1 prefix offsets of ALL texts
+ * (host).  Each replica runs its tower on its own stream and host thread, then ONE grouped ncclAllGather leaves [n_devices *
+ * rows_per_device][projection_dim] on every device (clip_amd_gathered_embeddings); vec (host, [total][projection_dim]) may be NULL.
+ * Synchronous: returns when every replica stream has finished.  clip_amd_image_batch_encode_u8 and clip_text_batch_encode shard the
+ * same way on such a handle when total >= 2 * n_devices. */
+bool clip_amd_image_batch_encode_device_multi(struct clip_ctx * ctx, const float * const * d_imgs, int total, bool normalize, float * vec);
+bool clip_amd_text_batch_encode_device_multi(struct clip_ctx * ctx, const int32_t * const * d_ids, const int32_t * h_offsets, int total, bool normalize,
+                                             float * vec);
+
 /* Which device a ctx lives on (-1: host-only ctx, see CLIP_AMD_ALLOW_NO_DEVICE in DESIGN.md). */
 int clip_amd_ctx_device(const struct clip_ctx * ctx);
 

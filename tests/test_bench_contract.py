@@ -33,7 +33,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     ws = d["whole_step_roofline"]
     assert ws["bound"] in ("mfma", "hbm") and 0 < ws["frac"] <= 1.0 and ws["algorithmic_flops_per_step"] > 0
     assert d["host_api_images_per_s"] > 0 and d["config"]["name"] == "custom"
-    assert "traffic" in rf and "traffic_note" in rf
+    assert "traffic" in rf and "traffic_note" in rf and 0 < rf["frac_8d"] <= 1.0
 
 
 def test_bench_collective_path_runs_with_one_rank():
@@ -49,6 +49,18 @@ def test_bench_collective_path_runs_with_one_rank():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_single_process_multi_gpu_form_runs_with_one_replica():
+    """bench.py --single-process: the SURVEY 8(e) implementation on the measured path — clip_amd_model_load_multi, device-resident
+    shards, the grouped ncclAllGather (one replica here: CLIP_AMD_MULTI_FORCE_RCCL) — prints the same contract line."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--single-process", "--steps", "3", "--warmup", "1", "--preheat", "0.2", "--model", "tiny",
+                        "--ftype", "q4_0", "--batch", "16"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and "single-process" in d["config"]["parallelism"]
 
 
 def test_graft_entry_smoke_runs():

@@ -108,3 +108,51 @@ def test_rccl_all_gather_path_with_two_devices(clip_lib, fixture_cache):
                 t = torch.empty((B, 32), dtype=torch.float32, device="cuda:%d" % g)
                 C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), B * 32 * 4, 3)
                 assert np.array_equal(t.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 2, 3])
+def test_sharded_u8_text_and_device_resident_entry_points(clip_lib, fixture_cache, G, monkeypatch):
+    """besides the f32 host path, clip_amd_image_batch_encode_u8 and clip_text_batch_encode shard on a
+    clip_amd_model_load_multi handle, and the device-resident forms (what bench.py --single-process measures) take per-device shard
+    pointers.  Replicas share device 0 where fewer than G devices exist (per-replica copies replace the collective there); with G
+    devices the grouped ncclAllGather runs and the gathered buffer is checked on every device."""
+    torch = pytest.importorskip("torch")
+    if clip_lib.device_count() < 1:
+        pytest.fail("GPU tier needs a HIP device")
+    if clip_lib.device_count() < G:
+        monkeypatch.setenv("CLIP_AMD_MULTI_OVERSUBSCRIBE", "1")
+    ndev = clip_lib.device_count()
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=True, vision=True)
+    single = clip_lib.Clip(p, device=0)
+    multi = clip_lib.Clip(p, n_devices=G)
+    rng = np.random.default_rng(9)
+    # raw u8 images of mixed sizes: 16 per call -> shards of ceil(16 / G); every shard has >= 4 images (68+ rows: the folded chain everywhere)
+    raws = [rng.integers(0, 256, size=(int(rng.integers(30, 90)), int(rng.integers(30, 90)), 3), dtype=np.uint8) for _ in range(16)]
+    assert np.array_equal(multi.encode_images_u8(raws), single.encode_images_u8(raws))
+    # ragged texts: 40 texts of 20-30 tokens: > 64 rows per shard
+    texts = fixtures.synthetic_token_ids(40, seed=3, min_len=20, max_len=30)
+    assert np.array_equal(multi.encode_texts(texts), single.encode_texts(texts))
+    # device-resident shards
+    B, S = 21, 32
+    imgs = fixtures.synthetic_images(B, S, seed=6)
+    want = single.encode_images(imgs)
+    keep, ptrs = [], []
+    for g in range(G):
+        lo, hi, per = clip_lib.shard_bounds(B, G, g)
+        t = torch.from_numpy(imgs[lo:hi].copy()).to("cuda:%d" % (g % ndev))
+        keep.append(t)
+        ptrs.append(t.data_ptr())
+    torch.cuda.synchronize()
+    out = np.empty((B, 32), dtype=np.float32)
+    multi.encode_images_device_multi(ptrs, B, True, out)
+    assert np.array_equal(out, want)
+    flat = [np.concatenate(texts[clip_lib.shard_bounds(40, G, g)[0]:clip_lib.shard_bounds(40, G, g)[1]]).astype(np.int32) for g in range(G)]
+    offs = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
+    tk = [torch.from_numpy(f).to("cuda:%d" % (g % ndev)) for g, f in enumerate(flat)]
+    torch.cuda.synchronize()
+    out_t = np.empty((40, 32), dtype=np.float32)
+    multi.encode_texts_device_multi([t.data_ptr() for t in tk], offs, True, out_t)
+    assert np.array_equal(out_t, single.encode_texts(texts))
+    multi.close()
+    single.close()
