@@ -500,83 +500,118 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
     return hipGraphLaunch(exec, ctx->stream) == hipSuccess;
 }
 
+// The vision tower of one workspace chunk in three stages, so that the host pipeline can run the first one per 32-image copy piece
+// while later pieces are still crossing PCIe (host_pipeline.cpp) and the layers ONCE on the whole chunk:
+//   vision_stage_begin : workspace for Bc images
+//   vision_stage_patch : images [i0, i0 + n) of the chunk: HWC -> im2col -> patch GEMM (+ position embedding) + class-token rows
+//   vision_stage_finish: pre-LN, the layers, pool + post-LN + projection + L2 for all Bc images
+bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st) {
+    const auto & hp = ctx->vision_hparams;
+    const DevTower & V = ctx->vision;
+    const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1;
+    const int h = hp.hidden_size, ff = hp.n_intermediate, proj = hp.projection_dim;
+    const int rows = Bc * T;
+    st.Bc = Bc;
+    st.st_stride = (rows + 63) & ~63;                      // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
+    auto carve = [&](Carver & c) {
+        st.stats = c.take<float2>((size_t)(h / 16) * st.st_stride);
+        st.x = c.take<float>((size_t)rows * h);
+        st.xn = c.take<half_t>((size_t)rows * h);
+        st.qkv = c.take<half_t>((size_t)rows * 3 * h);
+        st.att = c.take<half_t>((size_t)rows * h);
+        st.mid = c.take<half_t>((size_t)rows * ff);
+        st.col = c.take<half_t>((size_t)Bc * Np * V.patch.Kpad);
+        st.pooled = c.take<half_t>((size_t)Bc * h);
+        st.emb = c.take<float>((size_t)Bc * proj);
+    };
+    Carver sizer(nullptr);
+    carve(sizer);
+    if (!ensure_workspace(ctx, sizer.off + 4096)) return false;
+    Carver c(ctx->ws.base);
+    carve(c);
+    return true;
+}
+
+// imgs: the n images themselves (f32, or fp16 when ctx->input_f16), i0: their index inside the chunk
+bool vision_stage_patch(clip_ctx * ctx, const VisionStage & st, const void * imgs, int i0, int n) {
+    const bool piece = n < st.Bc;                             // part of a chunk: no split-K, so that the rows do not depend on the piece size
+    const auto & hp = ctx->vision_hparams;
+    const DevTower & V = ctx->vision;
+    const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1, h = hp.hidden_size;
+    hipStream_t s = ctx->stream;
+    half_t * col = st.col + (size_t)i0 * Np * V.patch.Kpad;
+    float * x = st.x + (size_t)i0 * T * h;
+    // patch embedding = im2col + GEMM (ggml_conv_2d, clip.cpp:1309-1312); epilogue scatters to token rows + pos
+    {
+        ProfScope ps(ctx, "im2col", n * Np, V.patch.Kpad, 0, 0, (double)n * S * S * 3 * (ctx->input_f16 ? 2 : 4) + (double)n * Np * V.patch.Kpad * 2);
+        launch_im2col(imgs, ctx->input_f16, col, n, S, P, V.patch.Kpad, s);
+    }
+    GemmParams pp;
+    pp.A = col; pp.lda = V.patch.Kpad; pp.M = n * Np; pp.W = V.patch; pp.out = x; pp.ldc = h;
+    pp.Np = Np; pp.T = T; pp.pos = V.pos; pp.no_splitk = piece;
+    gemm(ctx, "gemm_patch", pp, EPI_PATCH_F32);
+    launch_cls_rows(x, V.class_embd, V.pos, n, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
+    return true;
+}
+
+bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, bool normalize) {
+    const auto & hp = ctx->vision_hparams;
+    const DevTower & V = ctx->vision;
+    const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1;
+    const int h = hp.hidden_size, ff = hp.n_intermediate, nh = hp.n_head, proj = hp.projection_dim;
+    hipStream_t s = ctx->stream;
+    const int Bc = st.Bc, rows = Bc * T;
+    float * x = st.x;
+    const bool skinny = layers_fit_skinny(V, rows, h, ff);
+    const bool fold = ctx->ln_fold && !V.layers.empty();
+    {
+        ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
+        if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
+            launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, st.xn, h, st.stats, s);
+        else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
+    }
+    if (skinny && fold) {
+        if (!run_layers_skinny_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride)) return false;
+    } else if (skinny) {
+        launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
+        if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.qkv, st.att, st.mid)) return false;
+    } else if (fold) {
+        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride)) return false;
+    } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid)) return false;
+    // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
+    launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
+    GemmParams pj;
+    pj.A = st.pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = st.emb; pj.ldc = proj;
+    gemm(ctx, "gemm_proj", pj, EPI_F32);   // projection, no bias (:1443)
+    launch_l2norm(st.emb, d_out, Bc, proj, normalize, s);  // (:1446-1455)
+    return launch_ok("clip_image_batch_encode");
+}
+
+int vision_max_chunk(const clip_ctx * ctx) {
+    const auto & hp = ctx->vision_hparams;
+    const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1;
+    const int h = hp.hidden_size, ff = hp.n_intermediate;
+    // images are processed in chunks so that the workspace stays bounded (<= ~6 GB even for ViT-H)
+    const size_t per_img = (size_t)T * ((size_t)h * 4 + (size_t)h * 2 * 2 + (size_t)3 * h * 2 + (size_t)ff * 2) + (size_t)Np * ctx->vision.patch.Kpad * 2;
+    return (int)std::min<size_t>(1024, std::max<size_t>(1, ((size_t)6 << 30) / per_img));
+}
+
 static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
         return false;
     }
     if (B <= 0) return true;
-    const auto & hp = ctx->vision_hparams;
-    const DevTower & V = ctx->vision;
-    const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1;
-    const int h = hp.hidden_size, ff = hp.n_intermediate, nh = hp.n_head, proj = hp.projection_dim;
-    hipStream_t s = ctx->stream;
-
-    // images are processed in chunks so that the workspace stays bounded (<= ~6 GB even for ViT-H)
-    const size_t per_img = (size_t)T * ((size_t)h * 4 + (size_t)h * 2 * 2 + (size_t)3 * h * 2 + (size_t)ff * 2) + (size_t)Np * V.patch.Kpad * 2;
-    int chunk = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, ((size_t)6 << 30) / per_img));
-    chunk = std::min(chunk, 1024);
-
+    const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
+    const int chunk = std::min(B, vision_max_chunk(ctx));
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
-        const int rows = Bc * T;
-        Carver sizer(nullptr);
-        const int st_stride = (rows + 63) & ~63;               // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
-        float2 * stats = nullptr;
-        auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& col,
-                         half_t *& pooled, float *& emb) {
-            stats = c.take<float2>((size_t)(h / 16) * st_stride);
-            x = c.take<float>((size_t)rows * h);
-            xn = c.take<half_t>((size_t)rows * h);
-            qkv = c.take<half_t>((size_t)rows * 3 * h);
-            att = c.take<half_t>((size_t)rows * h);
-            mid = c.take<half_t>((size_t)rows * ff);
-            col = c.take<half_t>((size_t)Bc * Np * V.patch.Kpad);
-            pooled = c.take<half_t>((size_t)Bc * h);
-            emb = c.take<float>((size_t)Bc * proj);
-        };
-        float *x, *emb;
-        half_t *xn, *qkv, *att, *mid, *col, *pooled;
-        carve(sizer, x, xn, qkv, att, mid, col, pooled, emb);
-        if (!ensure_workspace(ctx, sizer.off + 4096)) return false;
-        Carver c(ctx->ws.base);
-        carve(c, x, xn, qkv, att, mid, col, pooled, emb);
-
+        VisionStage st;
+        if (!vision_stage_begin(ctx, Bc, st)) return false;
         // (host-pointer path: the staging buffer holds fp16 pixels, converted while packing — host_pipeline.cpp)
         const void * imgs = ctx->input_f16 ? (const void *)((const half_t *)d_imgs + (size_t)b0 * S * S * 3) : (const void *)(d_imgs + (size_t)b0 * S * S * 3);
-        // patch embedding = im2col + GEMM (ggml_conv_2d, clip.cpp:1309-1312); epilogue scatters to token rows + pos
-        {
-            ProfScope ps(ctx, "im2col", Bc * Np, V.patch.Kpad, 0, 0, (double)Bc * S * S * 3 * (ctx->input_f16 ? 2 : 4) + (double)Bc * Np * V.patch.Kpad * 2);
-            launch_im2col(imgs, ctx->input_f16, col, Bc, S, P, V.patch.Kpad, s);
-        }
-        GemmParams pp;
-        pp.A = col; pp.lda = V.patch.Kpad; pp.M = Bc * Np; pp.W = V.patch; pp.out = x; pp.ldc = h;
-        pp.Np = Np; pp.T = T; pp.pos = V.pos;
-        gemm(ctx, "gemm_patch", pp, EPI_PATCH_F32);
-        launch_cls_rows(x, V.class_embd, V.pos, Bc, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
-        const bool skinny = layers_fit_skinny(V, rows, h, ff);
-        const bool fold = ctx->ln_fold && !V.layers.empty();
-        {
-            ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
-            if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
-                launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, xn, h, stats, s);
-            else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
-        }
-        if (skinny && fold) {
-            if (!run_layers_skinny_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid, stats, st_stride)) return false;
-        } else if (skinny) {
-            launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
-            if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, qkv, att, mid)) return false;
-        } else if (fold) {
-            if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid, stats, st_stride)) return false;
-        } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, xn, qkv, att, mid)) return false;
-        // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
-        launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, pooled, h, nullptr, 0, s);
-        GemmParams pj;
-        pj.A = pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = emb; pj.ldc = proj;
-        gemm(ctx, "gemm_proj", pj, EPI_F32);   // projection, no bias (:1443)
-        launch_l2norm(emb, d_out + (size_t)b0 * proj, Bc, proj, normalize, s);  // (:1446-1455)
-        if (!launch_ok("clip_image_batch_encode")) return false;
+        if (!vision_stage_patch(ctx, st, imgs, 0, Bc)) return false;
+        if (!vision_stage_finish(ctx, st, d_out + (size_t)b0 * proj, normalize)) return false;
     }
     return true;
 }

@@ -582,7 +582,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
     const int tiles = ((p.M + bm - 1) / bm) * ((p.W.N + bn - 1) / bn), nk = p.W.Kpad / BK;
     if (heuristic) ksplit = ring ? pick_ksplit_ring(tiles, nk, p.W.wtype != W_F16) : pick_ksplit(tiles, nk);
     if (ksplit < 1) ksplit = 1;
-    if (bm != 64 || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n) ksplit = 1;
+    if (bm != 64 || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n || p.no_splitk) ksplit = 1;
     if (ksplit > nk / 2) ksplit = nk / 2 > 0 ? nk / 2 : 1;
     while (ksplit > 1 && (size_t)tiles * ksplit * bm * bn > p.sk_ws_floats) ksplit--;
     p.ksplit = ksplit;

@@ -80,6 +80,7 @@ struct GemmParams {
     unsigned * sk_cnt = nullptr;
     int sk_cnt_n = 0;
     int ksplit = 1;
+    bool no_splitk = false;   // never split K (the patch stage of the host pipeline runs per 32-image piece: its rows must carry the bits of the one-launch form)
     // large-M path (k_gemm8.hip): fp16 panel of a block-quantised W ([Npad][Kpad] row-major).  w16_pre != null: the panel was
     // already filled for this launch (per-layer dequantisation, forward.cpp); else launch_gemm fills w16_scratch
     // (>= Npad * Kpad halfs) itself when it picks that path; with neither, quantised weights stay on the fused 4-wave kernel.

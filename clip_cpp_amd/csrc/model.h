@@ -164,6 +164,17 @@ bool repack_for_test(int type, const void * w_raw, int64_t N, int64_t K, DevWeig
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize);
 bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets, int n_texts, float * d_out,
                          bool normalize);
+// the vision tower of one workspace chunk in stages (forward.cpp): the host pipeline runs the patch stage per copy piece
+struct VisionStage {
+    int Bc = 0, st_stride = 0;
+    float * x = nullptr, * emb = nullptr;
+    half_t * xn = nullptr, * qkv = nullptr, * att = nullptr, * mid = nullptr, * col = nullptr, * pooled = nullptr;
+    float2 * stats = nullptr;
+};
+bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st);
+bool vision_stage_patch(clip_ctx * ctx, const VisionStage & st, const void * imgs, int i0, int n);
+bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, bool normalize);
+int vision_max_chunk(const clip_ctx * ctx);
 bool ensure_workspace(clip_ctx * ctx, size_t bytes);
 bool ensure_pinned(clip_ctx * ctx, size_t bytes);
 bool ensure_io(clip_ctx * ctx, size_t in_bytes, size_t out_bytes);
