@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the text tower behind the vision tower on ONE stream (default: two contexts on two HIP streams, so "
                          "the small text kernels fill the tails of the vision kernels)")
+    ap.add_argument("--tower-priority", default="none", choices=["none", "text", "vision"],
+                    help="experiment: give one tower's HIP stream high priority (profiles/r03_lnfold_and_text_tiles.txt section 5)")
     ap.add_argument("--single-process", action="store_true",
                     help="SURVEY 8(e) form: ONE process, clip_amd_model_load_multi (a replica context + stream + host thread per GPU), "
                          "device-resident shards, ONE grouped ncclAllGather per tower — run as `python bench.py --gpus N --single-process` "
@@ -331,7 +333,7 @@ def main():
         tc = dict(tc, num_positions=77)
     S, proj = vc["image_size"], vc["projection_dim"]
     # a dedicated (non-null) torch stream carries the HIP kernels AND the RCCL all-gather, so they are ordered
-    stream = torch.cuda.Stream()
+    stream = torch.cuda.Stream(priority=-1 if args.tower_priority == "vision" else 0)
     torch.cuda.set_stream(stream)
     clip.set_stream(stream.cuda_stream)
     # the two towers of a step are independent: the text tower gets its own context (own workspace; 2nd copy of the weights)
@@ -339,7 +341,7 @@ def main():
     overlap = n_texts > 0 and not args.no_overlap
     if overlap:
         clip_t = clip_cpp_amd.Clip(path, verbosity=0, device=local_rank)
-        tstream = torch.cuda.Stream()
+        tstream = torch.cuda.Stream(priority=-1 if args.tower_priority == "text" else 0)
         clip_t.set_stream(tstream.cuda_stream)
     else:
         clip_t, tstream = clip, None
