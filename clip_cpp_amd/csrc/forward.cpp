@@ -360,6 +360,19 @@ bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int n
     return true;
 }
 
+// The fold pays where the GEMMs run two workgroups per CU (k_gemm.hip, k_gemm_ring.hip): the statistics prologue and the xg / statistics
+// tail of one workgroup hide under the other's K loop.  The large-M kernels (k_gemm4.hip, k_gemm8.hip: ONE workgroup per CU) expose both
+// — measured r03cfg, ViT-L/14 f16 batch 256: FFN-down +128 us, out-projection +106 us, FFN-up +61 us, q/k/v +31 us per launch against
+// 2 x 82 us of LayerNorm launches saved per layer: 4374 img/s folded vs 4690 unfolded — so a tower whose layers touch those kernels at
+// this row count keeps the LayerNorm launches.
+bool fold_pays(const DevTower & tw, int rows) {
+    if (tw.layers.empty()) return false;
+    const DevLayer & l = tw.layers[0];
+    for (const DevWeight * w : {&l.qkv, &l.o, &l.ff1, &l.ff2})
+        if (gemm_tile_uses_panel(gemm_tile_for(rows, w->N, w->Kpad, w->wtype != W_F16))) return false;
+    return true;
+}
+
 bool check_device(clip_ctx * ctx, const char * who) {
     if (!ctx || ctx->device < 0) {
         fprintf(stderr, "%s: no HIP device bound to this context — the encoders have no CPU fallback\n", who);
@@ -563,7 +576,7 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
     const int Bc = st.Bc, rows = Bc * T;
     float * x = st.x;
     const bool skinny = layers_fit_skinny(V, rows, h, ff);
-    const bool fold = ctx->ln_fold && !V.layers.empty();
+    const bool fold = ctx->ln_fold && (ctx->ln_fold_force || fold_pays(V, rows));
     {
         ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
         if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
@@ -692,7 +705,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     }
     auto launch_all = [&]() -> bool {
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
-        const bool fold = ctx->ln_fold && !Tw.layers.empty();
+        const bool fold = ctx->ln_fold && (ctx->ln_fold_force || fold_pays(Tw, rows));
         if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
             launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats);
         else launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)

@@ -342,11 +342,13 @@ __device__ __forceinline__ f4 ln_apply(bool ln, const float2 & mr, const f4 & ac
 
 // ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15).
 // nbase / mbase: first weight row / activation row of this wave's sub-tile.
-template <int EPI, int TN, int TM>
+// FOLD = false compiles the LayerNorm-fold branches out (k_gemm4.hip: with 256 accumulator registers per lane the fold tail spills, and
+// a kernel that has its CU to itself exposes the tail anyway — forward.cpp fold_pays keeps such shapes on the LayerNorm launches)
+template <int EPI, int TN, int TM, bool FOLD = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
                                               bool ln_on, const float2 * rs_lane, half_t * stage = nullptr, int lane = 0) {
     const int N = p.W.N;
-    constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;   // epilogues that can consume a folded LayerNorm
+    constexpr bool LNE = FOLD && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16);   // epilogues that can consume a folded LayerNorm
     const bool ln = LNE && ln_on;      // rs_lane: (mean, rstd) of this lane's rows in LDS (ln_row_final + ln_rows_publish in the kernel)
     // Everything the K loop requested has landed.  Said with the BUILTIN so that hipcc's waitcnt pass sees it: an LDS-DMA request
     // (a FLAT-encoded instruction touching two address spaces) leaves that pass in its "pending flat" state, in which every later
@@ -402,7 +404,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
                 if (m < p.M) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = acc[a][b];
             }
         }
-        if (p.xg_out) resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp, stage, lane);
+        if constexpr (FOLD) {
+            if (p.xg_out) resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp, stage, lane);
+        }
         return;
     }
 #pragma unroll
@@ -513,9 +517,10 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
 // wave parks its (BM/2) x (BN/2) fp16 sub-tile in its own LDS region (rows padded to 136 B: conflict-free 8-byte writes)
 // and re-reads it row-contiguous, so every global store instruction writes 8 full 128-byte lines.
 // Requires BN/2 == 64, the whole n range of the wave inside N, and a 16-byte aligned output row (ldc % 8 == 0).
-template <int EPI, int TN, int TM>
+template <int EPI, int TN, int TM, bool FOLD = true>
 __device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f4 (&acc)[TN][TM], int nbase, int mbase, int frow, int fgrp,
-                                                         half_t * stage, int lane, bool ln, const float2 * rs_lane) {
+                                                         half_t * stage, int lane, bool ln_on, const float2 * rs_lane) {
+    const bool ln = FOLD && ln_on;
     constexpr int RS = 68;                                     // halfs per staged row (64 + 4 pad = 136 B)
     __builtin_amdgcn_s_waitcnt(0x0070);                        // (see gemm_epilogue: lets hipcc count its waits again)
     f4 biasv[TN];                                              // one batch of loads, not TN dependent round trips

@@ -566,10 +566,11 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
-            if (tile % 1000 == 259) {
+            if (tile % 1000 == 259 && !p.ln_c && !p.xg_out) {
                 launch_gemm4(p, epilogue, stream);
                 return;
             }
+            if (tile % 1000 == 259) tile = 256256;     // LayerNorm-folded launch: the four-wave kernel carries no fold code, the 8-wave 256 x 256 tile does
             launch_gemm8(p, epilogue, tile / 32000, stream);
             return;
         }

@@ -182,15 +182,6 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     const bool stamper = p.sk_ws && tid == 0;
     if (stamper) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-    // LayerNorm folded into this GEMM (gemm_common.h): thread t (< BM = 256) reduces the statistics of row m0 + t to (mean, rstd) before
-    // the first request — the counted waits below then see only tile requests; the epilogue picks the values up through LDS
-    constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
-    const bool ln = LNE && p.ln_c != nullptr;
-    float2 ln_mine = make_float2(0.f, 1.f);
-    if constexpr (LNE) {
-        if (ln) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
-        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0), as a builtin: hipcc's own counting restarts from zero
-    }
     // prologue: tiles 0 and 1 requested, tile 0 awaited, its first k-slice read
     G4_ISSUE(0, 0);
     if (T > 1) {
@@ -244,28 +235,19 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();
 #endif
     const int nb = n0 + wn * 128, mb = m0 + wm * 128;
-    // LDS after the K loop: 4 fp16 staging areas of 128 rows x 136 bytes (69.6 KB), then 256 float2 of row statistics at 72 KB
-    half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
-    float2 * ln_rs = (float2 *)(smem + 72 * 1024);     // LayerNorm folded into this GEMM: (mean, rstd) of the tile's 256 rows
-    if constexpr (LNE) {
-        if (ln) ln_rows_publish(ln_rs, ln_mine, tid, BM, [] { __syncthreads(); });
-    }
-    const float2 * rs_lane = ln_rs + wm * 128 + frow;
+    // (no LayerNorm fold in this kernel: FOLD = false — gemm_common.h; launch_gemm sends folded launches to the 8-wave 256 x 256 tile)
     bool done = false;
-    if constexpr (LNE) {
+    if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
         if (nb + 128 <= p.W.N && (p.ldc & 7) == 0) {
-            if (!ln) raw_barrier4();                   // every wave is done with the ring: it becomes the staging area
+            raw_barrier4();                            // every wave is done with the ring: it becomes the staging area
+            half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
             typedef f4 half_acc_t[4][TM];
-            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane, ln, rs_lane);
-            gemm_epilogue_f16_staged<EPI, 4, TM>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane, ln, rs_lane);
+            gemm_epilogue_f16_staged<EPI, 4, TM, false>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane, false, nullptr);
+            gemm_epilogue_f16_staged<EPI, 4, TM, false>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane, false, nullptr);
             done = true;
         }
     }
-    if (!done) {
-        const bool staged = EPI == EPI_RESID_F32 && p.xg_out != nullptr;
-        if (staged) raw_barrier4();                    // producer half of the fold: xg goes through the staging areas
-        gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, rs_lane, staged ? stage : nullptr, lane);
-    }
+    if (!done) gemm_epilogue<EPI, TN, TM, false>(p, acc, nb, mb, frow, fgrp, false, nullptr);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();       // stores issued (not necessarily landed)

@@ -577,6 +577,7 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail("LayerNorm fold vectors: kernel failed");
         const char * e = getenv("CLIP_AMD_LNFOLD");
         ctx->ln_fold = !(e && e[0] == '0');
+        ctx->ln_fold_force = e && e[0] == '2';       // tuning: fold even where forward.cpp fold_pays() says the LayerNorm launches are cheaper
     }
     if (verbosity >= 1) printf("\n%s: %zu MB of HBM allocated for weights on device %d\n", "clip_model_load", ctx->weights_bytes / 1024 / 1024, device);
     return ctx;

@@ -128,6 +128,7 @@ struct clip_ctx {
     // LayerNorm partial statistics of the small-M path (k_skinny.hip): two [128 slots][128 rows] float2 buffers, written by the
     // residual epilogues and read by the LayerNorm-fused projections of the next sub-layer
     float2 * sk_stats = nullptr;
+    bool ln_fold_force = false;      // CLIP_AMD_LNFOLD=2
     bool ln_fold = true;             // LayerNorm folded into the GEMM epilogues for > 64 rows (CLIP_AMD_LNFOLD=0: the two-launch form, for A/B)
     // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
     clipamd::half_t * w16_panel = nullptr;
