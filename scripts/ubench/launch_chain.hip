@@ -6,6 +6,7 @@
 //   empty   : s_endpgm only                                              -> dispatch + completion + boundary
 //   touch   : every thread reads 16 B written by the previous launch and writes 16 B (a dependent memory round trip through L2)
 //   stream  : every workgroup reads 64 KB (what a skinny GEMM workgroup pulls: weights + activation rows) and writes 1 KB
+//   xtouch  : as touch, but the 16 B come from the workgroup on the NEXT die (cross-XCD hand-off through the kernel boundary)
 // Output: microseconds per launch = chain time / 66.   Build: hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/launch_chain scripts/ubench/launch_chain.hip
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -21,6 +22,15 @@ __global__ void __launch_bounds__(256) k_touch(const float4 * __restrict__ in, f
     float4 v = in[i];
     v.x += 1.0f;
     out[i] = v;
+}
+
+// the same round trip, but every workgroup reads what ANOTHER XCD's workgroup wrote in the previous launch (block b runs on XCD b % 8:
+// block b + 1 is the neighbour die) — the case of a layer chain, where a row written by one die is read by all of them
+__global__ void __launch_bounds__(256) k_xtouch(const float4 * __restrict__ in, float4 * __restrict__ out) {
+    const int src = ((blockIdx.x + 1) % gridDim.x) * 256 + threadIdx.x;
+    float4 v = in[src];
+    v.x += 1.0f;
+    out[blockIdx.x * 256 + threadIdx.x] = v;
 }
 
 // 64 KB per workgroup: 256 threads x 16 loads x 16 B, all in flight, then one 16-byte store per 4th thread
@@ -48,14 +58,15 @@ int main() {
     CK(hipMemset(b, 0, n4 * sizeof(float4)));
     printf("# chain of %d dependent launches on one stream, %d repetitions; us per launch (wall clock around the chain, host synchronised at both ends)\n", CHAIN, REPS);
     printf("# %-8s %6s | %10s %10s\n", "body", "grid", "eager", "graph");
-    for (int body = 0; body < 3; body++) {
+    for (int body = 0; body < 4; body++) {
         for (int g : grids) {
             auto launch_chain = [&](hipStream_t st) {
                 for (int i = 0; i < CHAIN; i++) {
                     float4 * in = (i & 1) ? b : a, * out = (i & 1) ? a : b;
                     if (body == 0) hipLaunchKernelGGL(k_empty, dim3(g), dim3(256), 0, st);
                     else if (body == 1) hipLaunchKernelGGL(k_touch, dim3(g), dim3(256), 0, st, in, out);
-                    else hipLaunchKernelGGL(k_stream, dim3(g), dim3(256), 0, st, in, out, 4096);
+                    else if (body == 2) hipLaunchKernelGGL(k_stream, dim3(g), dim3(256), 0, st, in, out, 4096);
+                    else hipLaunchKernelGGL(k_xtouch, dim3(g), dim3(256), 0, st, in, out);
                 }
             };
             double us[2] = {0, 0};
@@ -81,7 +92,7 @@ int main() {
             us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (REPS * CHAIN);
             CK(hipGraphExecDestroy(exec));
             CK(hipGraphDestroy(graph));
-            printf("  %-8s %6d | %10.2f %10.2f\n", body == 0 ? "empty" : body == 1 ? "touch" : "stream", g, us[0], us[1]);
+            printf("  %-8s %6d | %10.2f %10.2f\n", body == 0 ? "empty" : body == 1 ? "touch" : body == 2 ? "stream" : "xtouch", g, us[0], us[1]);
             fflush(stdout);
         }
     }
