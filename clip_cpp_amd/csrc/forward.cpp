@@ -78,7 +78,8 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
     const bool panel = gemm_tile_uses_panel(tile) && wt == W_F16;
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double wb = wt == W_F16 ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);
-    const double by = wb + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4);   // fused residual: read + write
+    const double by = wb + (double)p.M * p.W.K * 2 + (double)p.M * p.W.N * (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16 ? 2 : epi == EPI_RESID_F32 ? 8 : 4)   // fused residual: read + write
+                      + (p.xg_out ? (double)p.M * p.W.N * 2 : 0.0);     // LayerNorm fold: the residual epilogue also writes the next GEMM's fp16 operand
     // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
     if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)

@@ -63,7 +63,9 @@ int clip_amd_ctx_device(const struct clip_ctx * ctx);
 /* Bind all subsequent launches of this ctx to an existing HIP stream (e.g. torch's current
  * stream, as an integer handle).  NULL restores the ctx's own stream.  A context is single-stream and
  * single-thread at any one time (it owns one activation workspace): the switch orders the new stream behind
- * everything still queued on the previous one. */
+ * everything still queued on the previous one — by recording an event on the PREVIOUS stream, so that stream must still
+ * exist when clip_amd_set_stream (and clip_free, which synchronises the stream in use) is called: switch the context back
+ * (or free it) BEFORE destroying a stream it was bound to. */
 void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream);
 
 /* Device-resident form of clip_image_batch_encode (reference clip.cpp:1247-1523):

@@ -6,10 +6,12 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r02}
 R="${GRAFT_REPO_ROOT:-/root/repo}"
+if [ "${PROFILE_ONLY:-0}" != "1" ]; then
 echo "== GPU tests" ; timeout 1500 python -m pytest tests/ -m gpu -q 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" | tail -12 | tee gpurun_out/${TAG}_tests.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
 echo "== bench" ; timeout 900 python bench.py --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -2 | cut -c1-4000 | tee gpurun_out/${TAG}_bench.log
-echo "== rocprof kernel trace (default config)" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "$R/bench.py" --steps 10 --warmup 3 --preheat 0.3 --no-cpu-baseline --no-roofline --no-host-api > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
+fi
+echo "== rocprof kernel trace (default config)" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "$R/bench.py" --steps 10 --warmup 3 --preheat 0.3 --no-matrix --no-cpu-baseline --no-roofline --no-host-api > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
 for f in $(find /tmp/prof_${TAG} -name "*kernel_stats*.csv"); do grep -v "at::native\|__amd_rocclr" $f | cut -c1-400 > gpurun_out/${TAG}_kernel_stats_b32_q4_0_b256.csv; done
 head -8 gpurun_out/${TAG}_kernel_stats_b32_q4_0_b256.csv | cut -c1-200
 echo "== rocprof kernel trace (batch 1, L/14 f16 batch 256)"
@@ -18,10 +20,11 @@ for f in $(find /tmp/prof_${TAG}_b1 -name "*kernel_stats*.csv"); do grep -v "at:
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_l14 -o l14 -- python "$R/bench.py" --config cfg3_l14_f16_b256_img --steps 3 --warmup 1 --preheat 0.3 --no-cpu-baseline --no-roofline --no-host-api > /tmp/prof_l14.log 2>&1)
 for f in $(find /tmp/prof_${TAG}_l14 -name "*kernel_stats*.csv"); do grep -v "at::native\|__amd_rocclr" $f | cut -c1-400 > gpurun_out/${TAG}_kernel_stats_l14_f16_b256.csv; done
 head -6 gpurun_out/${TAG}_kernel_stats_b32_q4_0_b1.csv | cut -c1-160; head -6 gpurun_out/${TAG}_kernel_stats_l14_f16_b256.csv | cut -c1-160
+echo "== launch-boundary micro-benchmark"; [ -x scripts/ubench/launch_chain ] && timeout 300 ./scripts/ubench/launch_chain | tee gpurun_out/${TAG}_launch_chain.txt | tail -18
 echo "== rocprof PMC (HBM traffic, MFMA busy)"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $set | cut -d' ' -f1)
-  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$n -o pmc -- python "$R/bench.py" --steps 3 --warmup 1 --preheat 0 --no-cpu-baseline --no-roofline --no-host-api > /tmp/pmc_${TAG}_$n.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$n -o pmc -- python "$R/bench.py" --steps 3 --warmup 1 --preheat 0 --no-matrix --no-cpu-baseline --no-roofline --no-host-api > /tmp/pmc_${TAG}_$n.log 2>&1)
 done
 python - <<PY | tee gpurun_out/${TAG}_pmc_traffic_and_mfma_busy.txt
 import csv, glob, collections, json, sys
