@@ -325,7 +325,7 @@ __device__ __forceinline__ f4 dequant4(const uint8_t * row, int type, int k) {
         for (int e = 0; e < 4; e++) {
             const uint8_t q = blk[6 + ((j + e) & 15)];
             const int lo = j < 16 ? (q & 0x0F) : (q >> 4);
-            o[e] = (float)((lo | (((qh >> (j + e)) & 1) << 4)) - 16) * d;
+            o[e] = (float)((lo | (int)(((qh >> (j + e)) & 1u) << 4)) - 16) * d;   // (int): unsigned arithmetic would wrap below 16
         }
         return o;
     }
@@ -337,7 +337,7 @@ __device__ __forceinline__ f4 dequant4(const uint8_t * row, int type, int k) {
         for (int e = 0; e < 4; e++) {
             const uint8_t q = blk[8 + ((j + e) & 15)];
             const int lo = j < 16 ? (q & 0x0F) : (q >> 4);
-            o[e] = (float)(lo | (((qh >> (j + e)) & 1) << 4)) * d + m;
+            o[e] = (float)(lo | (int)(((qh >> (j + e)) & 1u) << 4)) * d + m;
         }
         return o;
     }
