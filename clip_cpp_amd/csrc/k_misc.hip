@@ -363,14 +363,22 @@ __global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restr
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    // position within its sequence: binary search seq_start (nseq+1 entries, ascending)
-    int lo = 0, hi = nseq;
+    // position within its sequence: 64-ary search of seq_start (nseq + 1 entries, ascending) — the 64 lanes probe 64 pivots per step, so
+    // 256 sequences take 2 dependent round trips (a binary search took 8, + 1 for the start: the launch was latency-, not bandwidth-bound)
+    const int id = ids[row];
+    int lo = 0, hi = nseq, start = seq_start[0];
     while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (seq_start[mid] <= row) lo = mid; else hi = mid;
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + (lane + 1) * step;
+        const int val = idx < hi ? seq_start[idx] : 0x7fffffff;
+        const int cnt = __popcll(__ballot(val <= row));               // pivots are ascending: the first cnt of them are <= row
+        if (cnt > 0) start = __shfl(val, cnt - 1, 64);
+        const int nlo = lo + cnt * step;
+        hi = min(hi, nlo + step);
+        lo = nlo;
     }
-    const int t = row - seq_start[lo];
-    const uint8_t * trow = tok + (size_t)ids[row] * tok_row_bytes;
+    const int t = row - start;
+    const uint8_t * trow = tok + (size_t)id * tok_row_bytes;
     f4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
