@@ -121,6 +121,28 @@ def test_text_tower_parity_at_model_shape(gpu, fixture_cache, config, ftype, n_t
     clip.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_texts", [65, 300, 4200])
+def test_text_batch_position_lookup_with_many_sequences(gpu, fixture_cache, n_texts):
+    """The embedding kernel finds a token row's sequence with a 64-ary search over the sequence starts (1 step up to 64 texts, 2 up to
+    4096, 3 beyond): a ragged batch of many short texts must give, row for row, what the same texts give in chunks of 50 (one-step
+    searches) — a wrong position index changes an embedding at the 1e-2 level, the GEMM schedules differ at 1e-7."""
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    clip = gpu.Clip(p, device=0)
+    npos = clip.text_config["num_positions"]
+    rng = np.random.default_rng(7000 + n_texts)
+    nv = clip.text_config["n_vocab"] if "n_vocab" in clip.text_config else 64
+    texts = [np.concatenate([[nv - 2], rng.integers(0, nv - 2, size=int(rng.integers(0, min(8, npos - 2) + 1))), [nv - 1]]).astype(np.int32)
+             for _ in range(n_texts)]
+    batch = clip.encode_texts(texts, normalize=True)
+    assert batch.shape[0] == n_texts and np.all(np.isfinite(batch))
+    chunks = np.concatenate([clip.encode_texts(texts[i:i + 50], normalize=True) for i in range(0, n_texts, 50)])
+    d = one_minus_cos(batch, chunks)
+    assert np.all(d <= 1e-6), (float(d.max()), int(d.argmax()))
+    np.testing.assert_allclose(batch, chunks, atol=1e-3)
+    clip.close()
+
+
 def want_n(orc, ids):
     return orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL)
 
