@@ -52,6 +52,9 @@ constexpr int NTHREADS = 256;
 // Quantised weights: one raw 32-weight block per thread in registers (two stages), dequantised into LDS.
 // Per K-step: issue DMA for tile k+1 + register loads for tile k+2, multiply tile k, dequant-store tile k+1, barrier
 // (the barrier's vmcnt(0) is what lands the DMA, so nothing inside a step waits on memory).
+// tiles instantiated with the deterministic split-K hand-off: every 64-row tile, and the 192 x 128 tile (text-tower FFN-down: 216 tiles for 512 slots)
+constexpr bool gemm_tile_splits_k(int bm, int bn) { return bm == 64 || (bm == 192 && bn == 128); }
+
 // ---------------------------------------------------------------------------------------------
 template <int WT, int BM, int BN, int EPI>
 __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2 : 1)) gemm_dma_kernel(const GemmParams p) {
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
 
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.W.N + BN - 1) / BN;
-    constexpr bool SK = (BM == 64);
+    constexpr bool SK = gemm_tile_splits_k(BM, BN);
     const int nwg = tiles_m * tiles_n * (SK ? p.ksplit : 1);
     int bid = blockIdx.x;
     {
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // split-K (BM = 64 tiles only, small-M problems): ksplit consecutive workgroups share one output tile, each
+    // split-K (BM = 64 tiles: small-M problems; 192 x 128 tiles: long-K GEMMs whose grid leaves CUs empty): ksplit consecutive workgroups share one output tile, each
     // multiplying a contiguous range of K-steps; see the fix-up after the main loop.
     const int ksplit = SK ? p.ksplit : 1;
     const int tile_id = SK ? bid / ksplit : bid;
@@ -369,7 +372,7 @@ void launch_dma(const GemmParams & p, hipStream_t stream) {
     static unsigned long long lds_ok = 0;
     if (smem > 64 * 1024) opt_in_dynamic_lds(gemm_dma_kernel<WT, BM, BN, EPI>, smem, lds_ok);
     int grid = tiles_m * tiles_n;
-    if (BM == 64) grid *= p.ksplit;   // p.ksplit validated by launch_gemm
+    if (gemm_tile_splits_k(BM, BN)) grid *= p.ksplit;   // p.ksplit validated by launch_gemm
     hipLaunchKernelGGL((gemm_dma_kernel<WT, BM, BN, EPI>), dim3(grid), dim3(NTHREADS), smem, stream, p);
 }
 
@@ -456,7 +459,7 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
     for (int bm : cand) {
         const float x = (float)wgs(bm, 128) / 512.f;
         const float g = x <= 0.5f ? 0.7f : x <= 1.f ? 1.f : 0.75f * x + 0.25f * ceilf(x);
-        const float cost = g * (float)(bm + 32) * (bm == 64 ? 1.15f : 1.f);
+        const float cost = g * (float)(bm + 32) * (bm == 64 ? 1.35f : 1.f);   // (1.15 until r03: the 4500-8000-row sweep has 128 x 128 ahead of 64 x 128 by 8-22 %)
         if (best_cost == 0.f || cost < best_cost) { best_cost = cost; best = bm * 1000 + 128; }
     }
     return best;
@@ -500,11 +503,11 @@ int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised) { return gemm_fo
 // Split-K factor for a BM = 64 tile grid (small-M problems: batch 1 / 32, single texts), fitted with
 // scripts/gemm_bench.py (profiles/r01_gemm_splitk.txt): a K-step costs ~0.5 us of serial latency, the fix-up ~3 us, so
 // splitting pays when the K loop is long — ksplit ~ sqrt(nk / 1.5) (12 steps -> 3, 48 -> 6) — and, once the grid already
-// fills the chip (>= 256 tiles), only for the long-K GEMMs (FFN down) and at most 4-way.
+// fills the chip (>= 256 tiles), not at all (profiles/r03_midlarge_sweep.txt).
 int pick_ksplit(int tiles, int nk) {
     if (nk < 8) return 1;
     int ks = (int)(sqrtf((float)nk / 1.5f) + 0.5f);
-    if (tiles >= 256) ks = nk >= 32 ? (ks < 4 ? ks : 4) : 1;
+    if (tiles >= 256) ks = 1;      // (r03 sweep, 4500-8000 rows x K = 2048 / 3072: 3-4-way splits of 284-500 tiles ran 15-45 % SLOWER than unsplit)
     if (tiles * ks > 1536) ks = 1536 / tiles;
     return ks < 1 ? 1 : ks > 16 ? 16 : ks;
 }
@@ -514,6 +517,15 @@ int pick_ksplit_ring(int tiles, int nk, bool quantised) {
     if (nk < 32) return 1;
     if (quantised) return tiles <= 160 ? 3 : 1;
     return tiles <= 110 ? 2 : 1;
+}
+
+// Split-K for the 192 x 128 tile (built in r03): measured SLOWER on every text-tower shape it was meant for
+// (10290 x 512 x 2048: 38.2 us unsplit, 54.9 two-way, 62.2 three-way; x 512 x 512: 16.9 / 36.4; profiles/r03_lnfold_and_text_tiles.txt
+// section 6) — parking and re-reading 98 KB partial tiles costs more than the second resident workgroup gains.  The code path stays
+// (explicit tile codes 2192128 ..., tested) but the heuristic never takes it.
+int pick_ksplit_big(int tiles, int nk) {
+    (void)tiles; (void)nk;
+    return 1;
 }
 
 void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stream) {
@@ -583,9 +595,9 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
     int bn = tile % 1000;
     if (ring) bn = bn >= 128 ? 128 : 64;
     const int tiles = ((p.M + bm - 1) / bm) * ((p.W.N + bn - 1) / bn), nk = p.W.Kpad / BK;
-    if (heuristic) ksplit = ring ? pick_ksplit_ring(tiles, nk, p.W.wtype != W_F16) : pick_ksplit(tiles, nk);
+    if (heuristic) ksplit = ring ? pick_ksplit_ring(tiles, nk, p.W.wtype != W_F16) : bm == 64 ? pick_ksplit(tiles, nk) : pick_ksplit_big(tiles, nk);
     if (ksplit < 1) ksplit = 1;
-    if (bm != 64 || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n || p.no_splitk) ksplit = 1;
+    if (!gemm_tile_splits_k(bm, bn) || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n || p.no_splitk) ksplit = 1;
     if (ksplit > nk / 2) ksplit = nk / 2 > 0 ? nk / 2 : 1;
     while (ksplit > 1 && (size_t)tiles * ksplit * bm * bn > p.sk_ws_floats) ksplit--;
     p.ksplit = ksplit;
