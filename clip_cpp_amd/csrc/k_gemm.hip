@@ -428,7 +428,7 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
             if (t64 <= 260) return 65064;
             // (r03 sweep, 1600 x 2304 x 768 = the q/k/v GEMM of 32 ViT-B/32 images: 234 tiles of 128 x 128 run 12.7 us against 13.9 for 450
             //  ring tiles; at K = 512 (2560 x 1536: 480 ring tiles 11.2 vs 12.4) and below 400 tiles the ring stays ahead)
-            if (t128 <= 500) return nk >= 24 && t128 > 400 && wgs(128, 128) >= 200 ? 128128 : 65128;
+            if (t128 <= 500) return nk >= 12 && t128 > 400 && wgs(128, 128) >= 200 ? 128128 : 65128;      // (nk counts 64-wide K-tiles: K >= 768)
         } else if (!quantised) {
             if (t64 <= 340) return 65064;
         } else if (M >= 1024 && t128 <= 340) {
