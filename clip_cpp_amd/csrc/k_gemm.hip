@@ -426,9 +426,10 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
         const int tm = (M + 63) / 64, t64 = tm * ((N + 63) / 64), t128 = tm * ((N + 127) / 128), nk = Kpad / BK;
         if (nk < 32) {
             if (t64 <= 260) return 65064;
-            // (r03 sweep, 1600 x 2304 x 768 = the q/k/v GEMM of 32 ViT-B/32 images: 234 tiles of 128 x 128 run 12.7 us against 13.9 for 450
-            //  ring tiles; at K = 512 (2560 x 1536: 480 ring tiles 11.2 vs 12.4) and below 400 tiles the ring stays ahead)
-            if (t128 <= 500) return nk >= 12 && t128 > 400 && wgs(128, 128) >= 200 ? 128128 : 65128;      // (nk counts 64-wide K-tiles: K >= 768)
+            // (r03: at 1600 x 2304 x 768 — q/k/v of 32 ViT-B/32 images — 234 tiles of 128 x 128 run 12.7 us against 13.9 for the 450 ring tiles in
+            //  isolation and the vision tower gains 1.7 %, but with the text tower on the second stream the step LOSES 4.5 %: the 64 KB
+            //  workgroups leave the text kernels no room on the CUs; same-box A/B in profiles/r03_lnfold_and_text_tiles.txt section 6.  The ring stays.)
+            if (t128 <= 500) return 65128;
         } else if (!quantised) {
             if (t64 <= 340) return 65064;
         } else if (M >= 1024 && t128 <= 340) {
