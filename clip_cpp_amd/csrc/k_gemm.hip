@@ -52,8 +52,10 @@ constexpr int NTHREADS = 256;
 // Quantised weights: one raw 32-weight block per thread in registers (two stages), dequantised into LDS.
 // Per K-step: issue DMA for tile k+1 + register loads for tile k+2, multiply tile k, dequant-store tile k+1, barrier
 // (the barrier's vmcnt(0) is what lands the DMA, so nothing inside a step waits on memory).
-// tiles instantiated with the deterministic split-K hand-off: every 64-row tile, and the 192 x 128 tile (text-tower FFN-down: 216 tiles for 512 slots)
-constexpr bool gemm_tile_splits_k(int bm, int bn) { return bm == 64 || (bm == 192 && bn == 128); }
+// tiles instantiated with the deterministic split-K hand-off: the 64-row tiles.  (r03 also instantiated it for the 192 x 128 tile — VERDICT r2
+// item 1 —: slower on every text-tower shape, and the extra code cost the split-free FFN-up launch 25 % (49.9 -> 62.6 us); removed again,
+// the implementation is in commit 8f8234b, the numbers in profiles/r03_lnfold_and_text_tiles.txt section 6.)
+constexpr bool gemm_tile_splits_k(int bm, int bn) { return bm == 64 && bn > 0; }
 
 // ---------------------------------------------------------------------------------------------
 template <int WT, int BM, int BN, int EPI>
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // split-K (BM = 64 tiles: small-M problems; 192 x 128 tiles: long-K GEMMs whose grid leaves CUs empty): ksplit consecutive workgroups share one output tile, each
+    // split-K (BM = 64 tiles only, small-M problems): ksplit consecutive workgroups share one output tile, each
     // multiplying a contiguous range of K-steps; see the fix-up after the main loop.
     const int ksplit = SK ? p.ksplit : 1;
     const int tile_id = SK ? bid / ksplit : bid;
@@ -520,15 +522,6 @@ int pick_ksplit_ring(int tiles, int nk, bool quantised) {
     return tiles <= 110 ? 2 : 1;
 }
 
-// Split-K for the 192 x 128 tile (built in r03): measured SLOWER on every text-tower shape it was meant for
-// (10290 x 512 x 2048: 38.2 us unsplit, 54.9 two-way, 62.2 three-way; x 512 x 512: 16.9 / 36.4; profiles/r03_lnfold_and_text_tiles.txt
-// section 6) — parking and re-reading 98 KB partial tiles costs more than the second resident workgroup gains.  The code path stays
-// (explicit tile codes 2192128 ..., tested) but the heuristic never takes it.
-int pick_ksplit_big(int tiles, int nk) {
-    (void)tiles; (void)nk;
-    return 1;
-}
-
 void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stream) {
     if (p0.M <= 0) return;
     GemmParams p = p0;
@@ -596,7 +589,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
     int bn = tile % 1000;
     if (ring) bn = bn >= 128 ? 128 : 64;
     const int tiles = ((p.M + bm - 1) / bm) * ((p.W.N + bn - 1) / bn), nk = p.W.Kpad / BK;
-    if (heuristic) ksplit = ring ? pick_ksplit_ring(tiles, nk, p.W.wtype != W_F16) : bm == 64 ? pick_ksplit(tiles, nk) : pick_ksplit_big(tiles, nk);
+    if (heuristic) ksplit = ring ? pick_ksplit_ring(tiles, nk, p.W.wtype != W_F16) : pick_ksplit(tiles, nk);
     if (ksplit < 1) ksplit = 1;
     if (!gemm_tile_splits_k(bm, bn) || !p.sk_ws || !p.sk_cnt || tiles > p.sk_cnt_n || p.no_splitk) ksplit = 1;
     if (ksplit > nk / 2) ksplit = nk / 2 > 0 ? nk / 2 : 1;

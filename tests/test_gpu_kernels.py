@@ -129,28 +129,6 @@ def test_gemm_split_k_is_deterministic_and_matches_unsplit(L, ksplit, tile, tnam
     assert np.abs(auto - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
 
 
-@pytest.mark.parametrize("ksplit", [2, 3])
-@pytest.mark.parametrize("tname,epi", [("q4_0", 4), ("f16", 3), ("q5_1", 1)])
-def test_gemm_split_k_on_the_192_row_tile(L, ksplit, tname, epi):
-    """Round 3: the 192 x 128 tile carries the same ordered split-K hand-off as the 64-row tiles (text-tower FFN-down: 216 tiles for 512
-    resident slots).  Deterministic, equal to the unsplit tile up to fp32 re-association, M / N edges included (a 100-row and an 80-column remainder)."""
-    rng = np.random.default_rng(300 + ksplit)
-    M, N, K = 192 * 3 + 100, 128 * 2 + 80, 2048
-    tid = ref.GGML_TYPES[tname]
-    raw = ref.quantize(tid, _weights(rng, N, K))
-    X = rng.standard_normal((M, K)).astype(np.float32)
-    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
-    resid = rng.standard_normal((M, N)).astype(np.float32)
-    code = ksplit * 1000000 + 192128
-    a = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=code)
-    b = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=code)
-    assert np.array_equal(a, b)
-    base = run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=1000000 + 192128)
-    assert np.array_equal(base, run_gemm(L, tid, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=64064))
-    assert not np.array_equal(a, base)                      # (it did split)
-    assert np.abs(a - base).max() <= 2e-3 * max(1.0, np.abs(base).max())
-
-
 RING_TILES = [65064, 65128]     # k_gemm_ring.hip: 64 activation rows x 64 / 128 weight rows, LDS ring of K-tiles
 
 
