@@ -41,18 +41,18 @@ HBM_PEAK_GBS = 8000.0
 
 # name -> model, file type, images per GPU per step, texts per GPU per step (None = same as images), default steps
 CONFIGS = {
-    "b32_q4_0_b256": dict(model="b32", ftype="q4_0", batch=256, texts=None, steps=20),   # BASELINE metric (default)
-    "b32_q4_0_b32": dict(model="b32", ftype="q4_0", batch=32, texts=None, steps=50),
-    "b32_q4_0_b1": dict(model="b32", ftype="q4_0", batch=1, texts=None, steps=100),
+    "b32_q4_0_b256": dict(model="b32", ftype="q4_0", batch=256, texts=None, steps=100),   # BASELINE metric (default)
+    "b32_q4_0_b32": dict(model="b32", ftype="q4_0", batch=32, texts=None, steps=200),
+    "b32_q4_0_b1": dict(model="b32", ftype="q4_0", batch=1, texts=None, steps=400),
     "l14_f16_b256": dict(model="l14", ftype="f16", batch=256, texts=None, steps=5),
-    "l14_f16_b32": dict(model="l14", ftype="f16", batch=32, texts=None, steps=20),
-    "l14_f16_b1": dict(model="l14", ftype="f16", batch=1, texts=None, steps=50),
+    "l14_f16_b32": dict(model="l14", ftype="f16", batch=32, texts=None, steps=40),
+    "l14_f16_b1": dict(model="l14", ftype="f16", batch=1, texts=None, steps=200),
     # BASELINE.json configs[1..4] (image encode only), single-GPU forms
-    "cfg2_b32_q4_0_b32_img": dict(model="b32", ftype="q4_0", batch=32, texts=0, steps=50),
+    "cfg2_b32_q4_0_b32_img": dict(model="b32", ftype="q4_0", batch=32, texts=0, steps=200),
     "cfg3_l14_f16_b256_img": dict(model="l14", ftype="f16", batch=256, texts=0, steps=5),
     "cfg4_l14_q5_1_b128_img": dict(model="l14", ftype="q5_1", batch=128, texts=0, steps=5),   # 1024 / 8 GPUs
     "cfg5_h14_q8_0_b64_img": dict(model="h14", ftype="q8_0", batch=64, texts=0, steps=5),
-    "b32_q4_0_b256_img": dict(model="b32", ftype="q4_0", batch=256, texts=0, steps=20),
+    "b32_q4_0_b256_img": dict(model="b32", ftype="q4_0", batch=256, texts=0, steps=100),
 }
 BITS_PER_WEIGHT = {"f32": 32.0, "f16": 16.0, "q4_0": 4.5, "q4_1": 5.0, "q5_0": 5.5, "q5_1": 6.0, "q8_0": 8.5}
 
