@@ -84,6 +84,7 @@ def parse():
                     help="SURVEY 8(e) form: ONE process, clip_amd_model_load_multi (a replica context + stream + host thread per GPU), "
                          "device-resident shards, ONE grouped ncclAllGather per tower — run as `python bench.py --gpus N --single-process` "
                          "(no torch.distributed.run); the default N > 1 form is one torch process per GPU")
+    ap.add_argument("--python-gc", action="store_true", help="leave CPython's cyclic garbage collector on (default: frozen + disabled for the run)")
     ap.add_argument("--no-matrix", action="store_true", help="default config only: skip the other cells of the north_star matrix")
     ap.add_argument("--matrix", action="store_true", help="run the matrix cells also with a non-default --config")
     ap.add_argument("--json-out", default=None)
@@ -290,6 +291,15 @@ def main():
 
     import clip_cpp_amd
     from clip_cpp_amd import synth   # synthetic GGUF through the product's own writer + clip_model_quantize (no oracle/ in the measured path)
+
+    if not args.python_gc:
+        # CPython's cyclic collector, with torch's heap behind it, pauses the launching thread for 35-40 ms once every few hundred steps
+        # (a full collection; scripts/step_spikes.py, profiles/r03_step_spikes.txt): a 200-step batch-32 cell read 53 k instead of 60 k
+        # emb/s when the pause fell into it.  Reference counting still frees everything this process allocates per step.
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
 
     cfg = dict(CONFIGS[args.config])
     if args.model: cfg["model"] = args.model

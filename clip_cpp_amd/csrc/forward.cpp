@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "model.h"
 
@@ -679,30 +680,54 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     carve(c, x, xn, qkv, att, mid, pooled, emb, seq, last);
     {
         // sequence offsets + last-token rows (EOS, clip.cpp:1154-1155): written into a slot of a pinned ring and uploaded
-        // asynchronously — the host does not wait for the stream (a slot is re-used 8 calls later; only then, and only if its
-        // upload is somehow still pending, does the event wait block)
+        // asynchronously by a one-workgroup launch that reads the (device-mapped) slot — the host does not wait for the stream; a slot is
+        // re-used 8 calls later, and only if its upload is somehow still pending then does the host spin on the stamp the launch leaves
         MetaRing & mr = ctx->meta;
         const int sl = mr.next;
         mr.next = (mr.next + 1) % MetaRing::SLOTS;
         const size_t n_ints = 2 * (size_t)n_texts + 1;
-        if (!mr.ev[sl] && hipEventCreateWithFlags(&mr.ev[sl], hipEventDisableTiming) != hipSuccess) return false;
-        if (mr.busy[sl]) (void)hipEventSynchronize(mr.ev[sl]);
+        if (!mr.done) {      // first text call of the context: the stamp array
+            unsigned * d = nullptr;
+            if (hipHostMalloc((void **)&d, MetaRing::SLOTS * sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+                memset(d, 0, MetaRing::SLOTS * sizeof(unsigned));
+                if (hipHostGetDevicePointer((void **)&mr.done_dev, d, 0) == hipSuccess) mr.done = d;
+                else { (void)hipGetLastError(); (void)hipHostFree(d); }
+            } else (void)hipGetLastError();
+        }
+        // the slot was last used SLOTS calls ago: wait until that upload has read it (normally long done)
+        if (mr.done && mr.expect[sl]) {
+            for (unsigned spins = 0; mr.done[sl] != mr.expect[sl]; spins++)
+                if (spins > 64) std::this_thread::yield();
+        } else if (mr.busy[sl]) {
+            (void)hipEventSynchronize(mr.ev[sl]);
+        }
         if (mr.cap[sl] < n_ints) {
             if (mr.pin[sl]) (void)hipHostFree(mr.pin[sl]);
             mr.pin[sl] = nullptr;
+            mr.dev[sl] = nullptr;
             mr.cap[sl] = 0;
             const size_t want = std::max<size_t>(n_ints, 1024);
-            if (hipHostMalloc((void **)&mr.pin[sl], want * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipHostMalloc((void **)&mr.pin[sl], want * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipHostGetDevicePointer((void **)&mr.dev[sl], mr.pin[sl], 0) != hipSuccess) { (void)hipGetLastError(); mr.dev[sl] = nullptr; }
             mr.cap[sl] = want;
         }
         int * hs = mr.pin[sl];
         for (int i = 0; i <= n_texts; i++) hs[i] = h_offsets[i] - h_offsets[0];
         for (int i = 0; i < n_texts; i++) hs[n_texts + 1 + i] = hs[i + 1] - 1;
-        // seq and last are carved back to back but 256-byte aligned: two copies
-        (void)hipMemcpyAsync(seq, hs, ((size_t)n_texts + 1) * 4, hipMemcpyHostToDevice, s);
-        (void)hipMemcpyAsync(last, hs + n_texts + 1, (size_t)n_texts * 4, hipMemcpyHostToDevice, s);
-        (void)hipEventRecord(mr.ev[sl], s);
-        mr.busy[sl] = true;
+        if (mr.done && mr.dev[sl]) {
+            if (++mr.stamp == 0) mr.stamp = 1;
+            mr.expect[sl] = mr.stamp;
+            mr.busy[sl] = false;
+            launch_meta_upload(mr.dev[sl], seq, last, n_texts, mr.done_dev + sl, mr.stamp, s);      // one launch reading the mapped slot
+        } else {
+            // fallback (the slot could not be mapped): two copies + an event.  seq and last are carved back to back but 256-byte aligned
+            if (!mr.ev[sl] && hipEventCreateWithFlags(&mr.ev[sl], hipEventDisableTiming) != hipSuccess) return false;
+            (void)hipMemcpyAsync(seq, hs, ((size_t)n_texts + 1) * 4, hipMemcpyHostToDevice, s);
+            (void)hipMemcpyAsync(last, hs + n_texts + 1, (size_t)n_texts * 4, hipMemcpyHostToDevice, s);
+            (void)hipEventRecord(mr.ev[sl], s);
+            mr.expect[sl] = 0;
+            mr.busy[sl] = true;
+        }
     }
     auto launch_all = [&]() -> bool {
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);

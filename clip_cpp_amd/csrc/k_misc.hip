@@ -572,6 +572,24 @@ void launch_layernorm_prep(const float * x, int ldx, const float * w, const floa
 #undef CLIPAMD_LNP
 }
 
+// The ragged-batch metadata of a text call (sequence starts, last-token rows) from a pinned, device-mapped host slot into the workspace,
+// by ONE workgroup; when the slot has been read it stamps `done` (mapped host memory) so that the host can re-use the slot without a HIP
+// event: hipEventRecord per call made the runtime stall once for ~35 ms after a few hundred to ~1000 calls (profiles/r03_step_spikes.txt).
+namespace {
+__global__ void __launch_bounds__(256) meta_upload_kernel(const int * __restrict__ src, int * __restrict__ seq, int * __restrict__ last, int n_texts,
+                                                          unsigned * done, unsigned stamp) {
+    for (int i = threadIdx.x; i < 2 * n_texts + 1; i += 256) {
+        const int v = src[i];
+        if (i <= n_texts) seq[i] = v; else last[i - n_texts - 1] = v;
+    }
+    __syncthreads();                      // every read of the slot has returned
+    if (threadIdx.x == 0) __hip_atomic_store(done, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+void launch_meta_upload(const int * src_mapped, int * seq, int * last, int n_texts, unsigned * done_mapped, unsigned stamp, hipStream_t stream) {
+    hipLaunchKernelGGL(meta_upload_kernel, dim3(1), dim3(256), 0, stream, src_mapped, seq, last, n_texts, done_mapped, stamp);
+}
+
 void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream) {
     if (rows <= 0) return;
     hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, v, out, rows, n, normalize ? 1 : 0);

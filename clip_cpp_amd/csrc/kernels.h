@@ -211,6 +211,7 @@ void launch_cls_rows(float * x, const float * class_embd, const float * pos, int
 
 // text embedding: x[r][:] = dequant(token_embd[ids[r]]) + pos[r - seq_start(r)]  (reference clip.cpp:1059-1061)
 // tok_raw is the token_embd tensor in its ggml block layout (type = ggml type id).
+void launch_meta_upload(const int * src_mapped, int * seq, int * last, int n_texts, unsigned * done_mapped, unsigned stamp, hipStream_t stream);
 void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw,
                        int tok_type, const float * pos, int h, float * x, hipStream_t stream,
                        const float * gamma_next = nullptr, half_t * xg = nullptr, int ldxg = 0, float2 * stats = nullptr);

@@ -595,6 +595,7 @@ void free_model(clip_ctx * ctx) {
             if (ctx->meta.pin[i]) (void)hipHostFree(ctx->meta.pin[i]);
             if (ctx->meta.ev[i]) (void)hipEventDestroy(ctx->meta.ev[i]);
         }
+        if (ctx->meta.done) (void)hipHostFree((void *)ctx->meta.done);
         if (ctx->ev_stream_switch) (void)hipEventDestroy(ctx->ev_stream_switch);
         for (auto & p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         drop_graphs(ctx);

@@ -74,10 +74,16 @@ struct HostPipe {
 struct MetaRing {
     static constexpr int SLOTS = 8;
     int * pin[SLOTS] = {nullptr};
+    int * dev[SLOTS] = {nullptr};     // the slot's device-side address (hipHostGetDevicePointer)
     size_t cap[SLOTS] = {0};
-    hipEvent_t ev[SLOTS] = {nullptr};
+    hipEvent_t ev[SLOTS] = {nullptr};     // (fallback path only: slots that could not be mapped)
     bool busy[SLOTS] = {false};
     int next = 0;
+    // slot hand-back without HIP events: the upload kernel stamps done[slot] (pinned, mapped) when it has read the slot
+    volatile unsigned * done = nullptr;   // [SLOTS], host view
+    unsigned * done_dev = nullptr;        // device view of the same memory
+    unsigned expect[SLOTS] = {0};         // the stamp the last upload from this slot will write (0 = never used)
+    unsigned stamp = 0;
 };
 
 }  // namespace clipamd
