@@ -88,7 +88,36 @@ def parse():
     ap.add_argument("--no-matrix", action="store_true", help="default config only: skip the other cells of the north_star matrix")
     ap.add_argument("--matrix", action="store_true", help="run the matrix cells also with a non-default --config")
     ap.add_argument("--json-out", default=None)
+    ap.add_argument("--no-rates", action="store_true", help="skip the separate image-only / text-only passes (PMC collection: every launch of the process then belongs to a W + K step)")
+    ap.add_argument("--stub-encoder", action="store_true",
+                    help="CPU test tier only (tests/test_bench_launch.py): torch CPU tensors, the gloo backend and a trivial stand-in for the two "
+                         "towers, so that the launcher, the collective skeleton and the JSON contract of this file run without a GPU; the line says so in `data`")
     return ap.parse_args()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher (the form the driver uses for N = 1): re-execute this command line under
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve).  Rank 0 of the child job prints
+    the JSON line on the inherited stdout; this process only forwards the exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode this pool's host driver supports (RCCL over xGMI needs it)
+    sys.stdout.flush()
+    # stdout of the job carries exactly the JSON line: anything else a rank's libraries print there (gloo's "[Gloo] Rank ... connected"
+    # banner in the CPU tier) is forwarded to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+    sys.stdout.flush()
+    raise SystemExit(proc.wait())
 
 
 def kernel_source_sha16():
@@ -181,17 +210,21 @@ def matrix_cell(torch, clip_cpp_amd, synth, cache, name, local_rank, steps=None,
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record(stream)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         step()
+        evs[i + 1].record(stream)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sm = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     assert bool(torch.isfinite(emb).all()), "non-finite embeddings in matrix cell %s" % name
     fl, by = algorithmic_work(vc, tc, cfg["ftype"], batch, [len(t) for t in texts])
     ms = dt / steps * 1e3
     t_mfma, t_hbm = fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
     out = {"name": name, "value": round((batch + n_texts) * steps / dt, 1), "unit": "embeddings/s" if n_texts else "images/s",
-           "ms_per_step": round(ms, 4), "steps": steps, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+           "ms_per_step": round(ms, 4), "ms_per_step_median": round(sm[len(sm) // 2], 4), "steps": steps, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
            "t_bound_us": round(max(t_mfma, t_hbm) * 1e6, 2), "whole_step_frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 4)}
     clip.close()
     if clip_t is not None:
@@ -210,8 +243,8 @@ L14_GEN_GUARD_S = 60.0
 
 def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, synth):
     """The C-ABI multi-GPU path on the measured path: one process, N replicas behind clip_amd_model_load_multi, shard g of
-    every batch resident on device g, the towers of a step back to back on each replica's stream, one grouped ncclAllGather (RCCL over
-    xGMI) of the embeddings per tower call.  Weak scaling: `batch` images + `n_texts` texts per GPU per step.  The calls are synchronous
+    every batch resident on device g, the two towers of a step on two streams per device (replica context + twin context, as the
+    one-process-per-GPU form), one grouped ncclAllGather (RCCL over xGMI) of both towers' embeddings per step.  Weak scaling: `batch` images + `n_texts` texts per GPU per step.  The calls are synchronous
     (they return when every replica stream has finished), so the timed region needs no further barrier."""
     N = args.gpus
     if clip_cpp_amd.device_count() < N:
@@ -243,9 +276,10 @@ def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, s
         torch.cuda.synchronize(g)
 
     def step():
-        clip.encode_images_device_multi(img_ptrs, N * batch, True)
-        if n_texts:
-            clip.encode_texts_device_multi(id_ptrs, offsets, True)
+        if n_texts:      # both towers of the step on two streams per device, one all-gather of both towers' rows
+            clip.encode_pair_device_multi(img_ptrs, N * batch, id_ptrs, offsets, True)
+        else:
+            clip.encode_images_device_multi(img_ptrs, N * batch, True)
 
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preheat:
@@ -266,8 +300,8 @@ def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, s
            "steps": steps, "warmup": args.warmup, "preheat_s": args.preheat, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
            "config": {"workload": "CLIP ViT-%s %s: %d images%s per GPU per step, shards resident in HBM, ONE process with a replica context + stream + "
-                                  "host thread per GPU (clip_amd_model_load_multi), towers back to back on each replica's stream, one grouped "
-                                  "ncclAllGather of the final embeddings per tower call" % (cfg["model"].upper(), cfg["ftype"], batch,
+                                  "host thread per GPU (clip_amd_model_load_multi), the two towers of a step on two streams per device "
+                                  "(clip_amd_encode_pair_device_multi), one grouped ncclAllGather of the final embeddings per step" % (cfg["model"].upper(), cfg["ftype"], batch,
                                                                                            (" + %d texts" % n_texts) if n_texts else ""),
                       "name": args.config, "images_per_gpu": batch, "texts_per_gpu": n_texts, "parallelism": "dp%d single-process" % N},
            "whole_step_roofline": {"bound": "mfma" if t_mfma_ws >= t_hbm_ws else "hbm", "algorithmic_flops_per_step": fl_step,
@@ -282,6 +316,97 @@ def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, s
         with open(args.json_out, "w") as f:
             f.write(line + "\n")
     clip.close()
+
+
+def timed_steps(args, steps, step, local_step, sync, local_sync, max_over_ranks, mark=None):
+    """The driver's timing contract, shared by the HIP path and the CPU-tier stub: untimed preheat (rank-local) + W warm-up steps, then EXACTLY
+    K steps between two (barrier + device synchronise) brackets; the time returned is the MAX over ranks."""
+    if args.preheat > 0:     # device preconditioning (clocks, code objects, allocator), not part of W or K
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.preheat:   # rank-local work only: iteration counts differ between ranks
+            local_step()
+            local_sync()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if mark:
+        mark(-1)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step()
+        if mark:
+            mark(i)
+    sync()
+    return max_over_ranks(time.perf_counter() - t0)
+
+
+def stub_main(args, cfg, steps, batch, n_texts, torch, dist, rank, world, N):
+    """--stub-encoder (CPU test tier): everything of the N-rank form of this file EXCEPT the HIP library — process group (gloo), per-rank
+    seeded inputs, the ONE all_gather_into_tensor of the final embeddings per step, barrier brackets, max-over-ranks time, one JSON line
+    from rank 0 — with a seeded linear map standing in for the towers.  Also checks the gathered buffer: block r must hold what rank r computes."""
+    use_dist = N > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="gloo")
+    proj, feat = 64, 192
+    gw = torch.Generator()
+    gw.manual_seed(7)
+    W = torch.randn((feat, proj), generator=gw)
+
+    def inputs(r):
+        g = torch.Generator()
+        g.manual_seed(1000 + r)
+        return torch.randn((batch + n_texts, feat), generator=g)
+
+    def towers(x):
+        y = x @ W
+        return y / y.norm(dim=1, keepdim=True)
+
+    x = inputs(rank)
+    emb = torch.empty((batch + n_texts, proj))
+    gathered = torch.empty((N * (batch + n_texts), proj)) if use_dist else None
+
+    def local_step():
+        emb.copy_(towers(x))
+
+    def step():
+        local_step()
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, emb)
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+
+    def max_over_ranks(dt):
+        if not use_dist:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dt = timed_steps(args, steps, step, local_step, sync, lambda: None, max_over_ranks)
+    if use_dist:
+        per = batch + n_texts
+        for r in range(world if N > 1 else 1):
+            assert torch.allclose(gathered[r * per:(r + 1) * per], towers(inputs(r)), atol=1e-6), "all-gather block %d is not rank %d's embeddings" % (r, r)
+    if rank == 0:
+        out = {"metric": "image+text embeddings/sec", "value": round(N * (batch + n_texts) * steps / dt, 1), "unit": "embeddings/s", "n_gpus": N,
+               "steps": steps, "warmup": args.warmup, "preheat_s": args.preheat, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub (CPU test tier: gloo ranks, a linear map instead of the HIP towers; NOT a measurement)",
+               "config": {"workload": "stub encoder, %d + %d rows per rank per step" % (batch, n_texts), "name": "stub", "parallelism": "dp%d" % N},
+               "roofline": None, "cpu_baseline": None, "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1"}
+        line = json.dumps(out)
+        print(line, flush=True)
+        if args.json_out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.json_out)), exist_ok=True)
+            with open(args.json_out, "w") as f:
+                f.write(line + "\n")
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def main():
@@ -320,10 +445,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
     if world != N:
+        if N > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BENCH_SELF_LAUNCHED") != "1":
+            self_launch(N)                       # does not return
         if N > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (N, world))
-    if not torch.cuda.is_available() or clip_cpp_amd.device_count() < 1:
+            raise SystemExit("bench.py --gpus %d: launched with WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must equal --gpus)" % (N, world))
+    stub = args.stub_encoder
+    if not stub and (not torch.cuda.is_available() or clip_cpp_amd.device_count() < 1):
         raise SystemExit("bench.py: no HIP device — the HIP path has no CPU fallback")
+    if stub:
+        return stub_main(args, cfg, steps, batch, n_texts, torch, dist, rank, world, N)
     torch.cuda.set_device(local_rank)
     # BENCH_FORCE_DIST=1: a single rank still initialises the RCCL process group and runs the all-gather / barrier / max-reduce of the
     # N > 1 path (one-rank collectives), so that path executes on a 1-GPU box (tests/test_bench_contract.py)
@@ -388,23 +518,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.preheat > 0:     # device preconditioning (clocks, code objects, allocator), not part of W or K
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.preheat:   # rank-local work only: iteration counts differ between ranks
-            local_step()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
+    # device-side step boundaries: one HIP event per step on the main stream (behind the join of the two towers / the all-gather), so the
+    # line can carry the MEDIAN step time next to the mean the contract asks for (median of >= 10 repetitions)
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+
+    def max_over_ranks(dt):
+        if not use_dist:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    dt = timed_steps(args, steps, step, local_step, sync, torch.cuda.synchronize, max_over_ranks, mark=lambda i: step_events[i + 1].record(stream))
+    step_ms = sorted(step_events[i].elapsed_time(step_events[i + 1]) for i in range(steps))
+    ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     per_step_units = N * (batch + n_texts)
     value = per_step_units * steps / dt
     assert bool(torch.isfinite(emb).all()), "non-finite embeddings"
@@ -419,8 +546,10 @@ def main():
         torch.cuda.synchronize()
         return units * n / (time.perf_counter() - t)
 
-    img_rate = rate(lambda: clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True), batch)
-    txt_rate = rate(lambda: clip.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True), n_texts) if n_texts else 0.0
+    img_rate = txt_rate = 0.0
+    if not args.no_rates:
+        img_rate = rate(lambda: clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True), batch)
+        txt_rate = rate(lambda: clip.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True), n_texts) if n_texts else 0.0
 
     # whole-step roofline: algorithmic work of one GPU's step against the measured step time
     fl_step, by_step = algorithmic_work(vc, tc, cfg["ftype"], batch, [len(t) for t in texts])
@@ -471,34 +600,41 @@ def main():
                         traffic_note = "pmc_traffic.json was measured on config %s" % tj.get("_config", "b32_q4_0_b256")
                     else:
                         traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                        whole["traffic_bytes_per_step"] = tj.get("_whole_step_hbm_bytes")      # PMC sum over every launch of a step (tracked round over round)
+                        if whole["traffic_bytes_per_step"]:
+                            whole["traffic_over_algorithmic"] = round(whole["traffic_bytes_per_step"] / by_step, 1)
                         traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2 x FETCH_SIZE + WRITE_SIZE (profiles/pmc_traffic.json)"
                 except Exception as e:   # noqa: BLE001
                     traffic_note = "unreadable pmc_traffic.json: %s" % e
-            # the binding roofline of this kernel: whichever of (algorithmic FLOPs / MFMA peak) and (algorithmic bytes / HBM peak) is
-            # the longer time.
+            # intermediates are not algorithmic, so the bound of a weight GEMM follows from its FLOPs per WEIGHT byte against the
+            # ridge (310 FLOP/B): MFMA-bound (algorithmic FLOPs / 2.5 PFLOP/s) above it, HBM-bound (weight bytes / 8 TB/s) below it.  That
+            # view is `roofline.frac`; the kernel-level HBM view — whose byte count also holds the activations, outputs and residual rows the
+            # launch really moves — is kept under `other_bound` (until r03 `frac` was whichever view took longer).
             fl_l, by_l = d["flops"] / d["launches"], d["bytes"] / d["launches"]
-            t_mfma, t_hbm = fl_l / (MFMA_F16_PEAK_TFLOPS * 1e12), by_l / (HBM_PEAK_GBS * 1e9)
+            wb_l = weight_only_bytes(d, rep, dom)
+            t_mfma, t_hbm_w = fl_l / (MFMA_F16_PEAK_TFLOPS * 1e12), wb_l / (HBM_PEAK_GBS * 1e9)
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            gbs_w = wb_l / (avg_ms * 1e-3) / 1e9
             mfma_view = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4)}
-            hbm_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
-            main, other = (hbm_view, mfma_view) if t_hbm > t_mfma else (mfma_view, hbm_view)
-            roofline = dict(main)
-            # intermediates are not algorithmic, so a weight GEMM at batch >= 2 is MFMA-bound and the fraction that follows
-            # is the MFMA view; `frac` above keeps the stricter of the two kernel-level views (the HBM view counts the activation and
-            # residual bytes the launch really moves)
-            roofline["frac_8d"] = mfma_view["frac"] if fl_l / max(1.0, weight_only_bytes(d, rep, dom)) > 310.0 else hbm_view["frac"]
-            roofline["frac_8d_note"] = "SURVEY 8(d) view: algorithmic FLOPs / 2.5 PFLOP/s when FLOPs per WEIGHT byte exceed the ridge (310 FLOP/B), else weight bytes / 8 TB/s"
+            hbm_w_view = {"bound": "hbm", "achieved": round(gbs_w, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_w / HBM_PEAK_GBS, 4),
+                          "note": "weight bytes only (SURVEY 8d)"}
+            hbm_k_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "note": "kernel-level view: weights + activations + outputs + residual rows of the launch"}
+            mfma_bound = t_mfma >= t_hbm_w          # FLOPs per weight byte above the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)
+            roofline = dict(mfma_view if mfma_bound else hbm_w_view)
+            other = hbm_k_view if mfma_bound else mfma_view
+            roofline["frac_8d"] = roofline["frac"]          # (kept for readers of the r03 line: the same number)
             roofline.update({"kernel": dom + " (fp16 MFMA weight GEMM; template args as in the rocprofv3 kernel name)",
                              "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
-                             "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l,
-                             "t_mfma_us": round(t_mfma * 1e6, 2), "t_hbm_us": round(t_hbm * 1e6, 2), "other_bound": other,
+                             "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l, "weight_bytes_per_launch": wb_l,
+                             "t_mfma_us": round(t_mfma * 1e6, 2), "t_hbm_us": round(t_hbm_w * 1e6, 2), "other_bound": other,
                              "shapes_MxNxK": sorted(d["shapes"]), "share_of_kernel_time": round(d["ms"] / total_ms, 3)})
             kernels = {k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None}
                        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:16]}
 
-    host_api = host_api_x4 = None
+    host_api = host_api_x4 = host_api_u8 = host_api_u8_x4 = None
     if not args.no_host_api and rank == 0 and N == 1:
         # the drop-in boundary itself: clip_image_batch_encode from the caller's pageable float buffers (H2D + D2H inside the call)
         h_imgs = imgs.cpu().numpy()
@@ -520,6 +656,22 @@ def main():
         host_api_x4 = round(4 * batch * reps4 / (time.perf_counter() - t), 1)
         del host_big
         del h_imgs
+        # ... and the raw-pixel entry point: clip_amd_image_batch_encode_u8 from pageable u8 images of the model's input size —
+        # 150 KB per image over PCIe instead of 602 KB, resize / crop / normalise on the GPU (bit-identical to clip_image_preprocess)
+        u8 = np.random.default_rng(5).integers(0, 256, (batch, S, S, 3), dtype=np.uint8)
+        clip.encode_images_u8(u8[: min(batch, 8)])
+        clip.encode_images_u8(u8)
+        t = time.perf_counter()
+        for _ in range(reps):
+            clip.encode_images_u8(u8)
+        host_api_u8 = round(batch * reps / (time.perf_counter() - t), 1)
+        u8_big = np.concatenate([u8] * 4, axis=0)
+        clip.encode_images_u8(u8_big)
+        t = time.perf_counter()
+        for _ in range(reps):
+            clip.encode_images_u8(u8_big)
+        host_api_u8_x4 = round(4 * batch * reps / (time.perf_counter() - t), 1)
+        del u8, u8_big
 
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and N == 1:
@@ -596,6 +748,12 @@ def main():
             "images_per_s_per_gpu": round(img_rate, 1), "texts_per_s_per_gpu": round(txt_rate, 1),
             "host_api_images_per_s": host_api,
             "host_api_images_per_s_4x_batch_per_call": host_api_x4,
+            "host_api_u8_images_per_s": host_api_u8,
+            "host_api_u8_images_per_s_4x_batch_per_call": host_api_u8_x4,
+            "ms_per_step_median": round(ms_median, 4), "ms_per_step_min": round(step_ms[0], 4), "ms_per_step_max": round(step_ms[-1], 4),
+            "ms_per_step_note": "ms_per_step = wall clock of the K steps / K (the contract); median / min / max = per-step HIP-event deltas on the main stream over the same K steps",
+            "python_gc": "enabled" if args.python_gc else "disabled (gc.freeze + gc.disable for the run: a caller's process does not get this; --python-gc leaves it on)",
+            "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
             "roofline": roofline, "whole_step_roofline": whole, "cpu_baseline": cpu_baseline, "matrix": matrix, "kernels": kernels,
             "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)",
         }

@@ -60,7 +60,8 @@ API_SYMBOLS = [
 ]
 AMD_SYMBOLS = [
     "clip_amd_device_count", "clip_amd_model_load", "clip_amd_model_load_multi", "clip_amd_ctx_device_count", "clip_amd_weights_from_cache", "clip_amd_shard_bounds",
-    "clip_amd_gathered_embeddings", "clip_amd_ctx_device", "clip_amd_set_stream",
+    "clip_amd_gathered_embeddings", "clip_amd_ctx_device", "clip_amd_set_stream", "clip_amd_image_batch_encode_device_multi",
+    "clip_amd_text_batch_encode_device_multi", "clip_amd_encode_pair_device_multi",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
@@ -156,6 +157,8 @@ def lib():
     L.clip_amd_image_batch_encode_device_multi.argtypes = [vp, C.POINTER(vp), i32, C.c_bool, f32p]
     L.clip_amd_text_batch_encode_device_multi.restype = C.c_bool
     L.clip_amd_text_batch_encode_device_multi.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, C.c_bool, f32p]
+    L.clip_amd_encode_pair_device_multi.restype = C.c_bool
+    L.clip_amd_encode_pair_device_multi.argtypes = [vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(C.c_int32), i32, C.c_bool, f32p, f32p]
     L.clip_amd_profile_enable.argtypes = [vp, C.c_bool]
     L.clip_amd_profile_report.restype = i32
     L.clip_amd_profile_report.argtypes = [vp, C.c_char_p, i32, C.c_bool]
@@ -306,37 +309,46 @@ class Clip:
 
     @staticmethod
     def _u8_array(images):
+        if isinstance(images, np.ndarray) and images.ndim == 4 and images.shape[0] > 0:
+            # one contiguous [B, ny, nx, 3] block: the clip_image_u8 array without a Python loop (as encode_images; ~7 us per ctypes object)
+            blk = np.ascontiguousarray(images, dtype=np.uint8)
+            B = blk.shape[0]
+            rec = np.empty(B, dtype=np.dtype([("nx", np.int32), ("ny", np.int32), ("data", np.uint64), ("size", np.uint64)], align=True))
+            assert rec.dtype.itemsize == C.sizeof(ClipImageU8)
+            rec["nx"], rec["ny"], rec["size"] = blk.shape[2], blk.shape[1], blk[0].size
+            rec["data"] = blk.ctypes.data + np.arange(B, dtype=np.uint64) * np.uint64(blk.strides[0])
+            return (blk, rec), C.cast(rec.ctypes.data, C.POINTER(ClipImageU8)), B
         keep = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
         arr = (ClipImageU8 * len(keep))()
         for i, im in enumerate(keep):
             arr[i] = ClipImageU8(im.shape[1], im.shape[0], im.ctypes.data_as(C.POINTER(C.c_uint8)), im.size)
-        return keep, arr
+        return keep, arr, len(keep)
 
     def encode_images_u8(self, images, normalize=True):
         """list of uint8 [ny,nx,3] raw images (any sizes) -> float32 [n,proj]; resize/crop/normalise run on the GPU
         (clip_amd_image_batch_encode_u8), bit-identical to preprocess() + encode_images()."""
-        keep, arr = self._u8_array(images)
-        out = np.empty((len(keep), self.vision_config["projection_dim"]), dtype=np.float32)
-        if not lib().clip_amd_image_batch_encode_u8(self.ctx, arr, len(keep), _fp(out), normalize):
+        keep, arr, n = self._u8_array(images)
+        out = np.empty((n, self.vision_config["projection_dim"]), dtype=np.float32)
+        if not lib().clip_amd_image_batch_encode_u8(self.ctx, arr, n, _fp(out), normalize):
             raise RuntimeError("clip_amd_image_batch_encode_u8 failed (see stderr)")
         return out
 
     def zero_shot_label_images(self, images, labels):
         """Batched clip_zero_shot_label_image on the GPU: list of uint8 [ny,nx,3] images x list of label strings ->
         (scores [B,n] sorted descending, indices [B,n])."""
-        keep, arr = self._u8_array(images)
+        keep, arr, B = self._u8_array(images)
         n = len(labels)
         lab = (C.c_char_p * n)(*[l.encode("utf-8") for l in labels])
-        scores = np.empty((len(keep), n), dtype=np.float32)
-        idx = np.empty((len(keep), n), dtype=np.int32)
-        if not lib().clip_amd_zero_shot_label_images(self.ctx, arr, len(keep), lab, n, _fp(scores), idx.ctypes.data_as(C.POINTER(C.c_int))):
+        scores = np.empty((B, n), dtype=np.float32)
+        idx = np.empty((B, n), dtype=np.int32)
+        if not lib().clip_amd_zero_shot_label_images(self.ctx, arr, B, lab, n, _fp(scores), idx.ctypes.data_as(C.POINTER(C.c_int))):
             raise RuntimeError("clip_amd_zero_shot_label_images failed (see stderr)")
         return scores, idx
 
     def preprocess_device(self, images, d_out_ptr):
         """list of uint8 [ny,nx,3] raw images -> [n,S,S,3] float32 at device address d_out_ptr (asynchronous)."""
-        keep, arr = self._u8_array(images)
-        if not lib().clip_amd_image_batch_preprocess_device(self.ctx, arr, len(keep), C.c_void_p(d_out_ptr)):
+        keep, arr, B = self._u8_array(images)
+        if not lib().clip_amd_image_batch_preprocess_device(self.ctx, arr, B, C.c_void_p(d_out_ptr)):
             raise RuntimeError("clip_amd_image_batch_preprocess_device failed (see stderr)")
         self.synchronize()   # `keep` (the host pixels) must outlive the copy into the pinned blob — it does: the copy is synchronous
 
@@ -409,6 +421,17 @@ class Clip:
                                                              _fp(out) if out is not None else None):
             raise RuntimeError("clip_amd_text_batch_encode_device_multi failed (see stderr)")
         return out
+
+    def encode_pair_device_multi(self, d_img_ptrs, n_images, d_ids_ptrs, offsets, normalize=True, out_img=None, out_txt=None):
+        """Multi-GPU handle: both towers of a step in one call (clip_amd_encode_pair_device_multi) — per device the vision tower on the
+        replica's stream and the text tower on a twin context's stream, ONE all-gather of both towers' rows."""
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        ia = (C.c_void_p * len(d_img_ptrs))(*[C.c_void_p(p) for p in d_img_ptrs])
+        ta = (C.c_void_p * len(d_ids_ptrs))(*[C.c_void_p(p) for p in d_ids_ptrs])
+        if not lib().clip_amd_encode_pair_device_multi(self.ctx, ia, n_images, ta, off.ctypes.data_as(C.POINTER(C.c_int32)), off.size - 1, normalize,
+                                                       _fp(out_img) if out_img is not None else None, _fp(out_txt) if out_txt is not None else None):
+            raise RuntimeError("clip_amd_encode_pair_device_multi failed (see stderr)")
+        return out_img, out_txt
 
     def gathered_embeddings_ptr(self, device_index=0):
         return lib().clip_amd_gathered_embeddings(self.ctx, device_index)

@@ -298,6 +298,28 @@ bool clip_amd_text_batch_encode_device_multi(struct clip_ctx * ctx, const int32_
                      });
 } catch (...) { fprintf(stderr, "clip_amd_text_batch_encode_device_multi: exception\n"); return false; }
 
+// Both towers of a step on a clip_amd_model_load_multi context, device-resident shards (bench.py --single-process): on every device the
+// vision tower (reference clip.cpp:1247) and the text tower (:1016) run on two streams (replica context + a twin context of the same
+// device), ONE grouped all-gather carries both towers' rows.  vec_img [n_images][proj] / vec_txt [n_texts][proj] on the host, or NULL.
+bool clip_amd_encode_pair_device_multi(struct clip_ctx * ctx, const float * const * d_imgs, int n_images, const int32_t * const * d_ids,
+                                       const int32_t * h_offsets, int n_texts, bool normalize, float * vec_img, float * vec_txt) try {
+    if (!ctx || !ctx->multi || !ctx->has_vision_encoder || !ctx->has_text_encoder || !d_imgs || !d_ids || !h_offsets) {
+        fprintf(stderr, "clip_amd_encode_pair_device_multi: needs a two-tower clip_amd_model_load_multi context\n");
+        return false;
+    }
+    if (n_images <= 0 || n_texts <= 0) { fprintf(stderr, "clip_amd_encode_pair_device_multi: needs images and texts\n"); return false; }
+    if (ctx->vision_hparams.projection_dim != ctx->text_hparams.projection_dim) { fprintf(stderr, "clip_amd_encode_pair_device_multi: the towers project to different widths\n"); return false; }
+    const int G = multi_device_count(ctx);
+    std::vector<std::vector<int32_t>> off(G);          // per-shard offsets rebased to 0 (alive until multi_run_pair has synchronised)
+    return multi_run_pair(ctx, n_images, n_texts, ctx->vision_hparams.projection_dim, vec_img, vec_txt, "clip_amd_encode_pair_device_multi",
+                          [&](int g, clip_ctx * c, int l, int h, float * d_send) { return vision_forward_device(c, d_imgs[g], h - l, d_send, normalize); },
+                          [&](int g, clip_ctx * c, int l, int h, float * d_send) {
+                              off[g].resize((size_t)(h - l) + 1);
+                              for (int i = l; i <= h; i++) off[g][(size_t)(i - l)] = h_offsets[i] - h_offsets[l];
+                              return text_forward_device(c, d_ids[g], off[g].data(), h - l, d_send, normalize);
+                          });
+} catch (...) { fprintf(stderr, "clip_amd_encode_pair_device_multi: exception\n"); return false; }
+
 // n ragged texts (host token lists) -> d_out [n][proj] on ctx's device, queued on ctx->stream.  ids / off: caller-owned staging that must
 // stay alive until the stream is synchronised (the upload of pageable memory may still be reading it).
 static bool texts_to_device(clip_ctx * ctx, const clip_tokens * tokens, size_t n_texts, std::vector<int32_t> & ids, std::vector<int32_t> & off,

@@ -578,7 +578,7 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
     const int Bc = st.Bc, rows = Bc * T;
     float * x = st.x;
     const bool skinny = layers_fit_skinny(V, rows, h, ff);
-    const bool fold = ctx->ln_fold && (ctx->ln_fold_force || fold_pays(V, rows));
+    const bool fold = ctx->ln_fold && !V.layers.empty() && (ctx->ln_fold_force || fold_pays(V, rows));
     {
         ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
         if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
@@ -696,8 +696,21 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         }
         // the slot was last used SLOTS calls ago: wait until that upload has read it (normally long done)
         if (mr.done && mr.expect[sl]) {
-            for (unsigned spins = 0; mr.done[sl] != mr.expect[sl]; spins++)
+            // bounded: after ~1 ms of yields fall back to the stream itself — a failed launch, a faulted stream or a stream
+            // under capture never writes the stamp, and the old event path reported exactly those cases as an error
+            for (unsigned spins = 0; mr.done[sl] != mr.expect[sl]; spins++) {
                 if (spins > 64) std::this_thread::yield();
+                if (spins > 20000) {
+                    const hipError_t qe = hipStreamSynchronize(s);
+                    if (qe != hipSuccess || mr.done[sl] != mr.expect[sl]) {
+                        fprintf(stderr, "clip_text_encode: the metadata upload of an earlier call never completed (%s)\n", hipGetErrorString(qe));
+                        (void)hipGetLastError();
+                        mr.expect[sl] = 0;
+                        if (qe != hipSuccess) return false;
+                    }
+                    break;
+                }
+            }
         } else if (mr.busy[sl]) {
             (void)hipEventSynchronize(mr.ev[sl]);
         }
@@ -719,6 +732,11 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
             mr.expect[sl] = mr.stamp;
             mr.busy[sl] = false;
             launch_meta_upload(mr.dev[sl], seq, last, n_texts, mr.done_dev + sl, mr.stamp, s);      // one launch reading the mapped slot
+            if (hipGetLastError() != hipSuccess) {      // the launch did not happen: nobody will stamp this slot
+                mr.expect[sl] = 0;
+                fprintf(stderr, "clip_text_encode: metadata upload launch failed\n");
+                return false;
+            }
         } else {
             // fallback (the slot could not be mapped): two copies + an event.  seq and last are carved back to back but 256-byte aligned
             if (!mr.ev[sl] && hipEventCreateWithFlags(&mr.ev[sl], hipEventDisableTiming) != hipSuccess) return false;
@@ -731,7 +749,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     }
     auto launch_all = [&]() -> bool {
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
-        const bool fold = ctx->ln_fold && (ctx->ln_fold_force || fold_pays(Tw, rows));
+        const bool fold = ctx->ln_fold && !Tw.layers.empty() && (ctx->ln_fold_force || fold_pays(Tw, rows));
         if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
             launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats);
         else launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)

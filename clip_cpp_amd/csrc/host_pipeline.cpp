@@ -376,6 +376,10 @@ struct MultiCtx {
     bool use_rccl = true;
     bool collective = false;              // the all-gather runs (G > 1, or G == 1 with CLIP_AMD_MULTI_FORCE_RCCL=1)
     PackPool replicas;                    // one persistent host thread per replica beyond the first (the caller drives replica 0)
+    // two-tower calls (multi_run_pair): a second context per device carries the text tower on its own stream (a context owns ONE
+    // activation workspace and ONE split-K workspace, so the towers of a step cannot share one), loaded on the first such call
+    std::vector<clip_ctx *> twin;
+    std::vector<hipEvent_t> ev_fork, ev_join;
 };
 
 clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
@@ -444,9 +448,29 @@ void multi_free(clip_ctx * primary) {
         if (mc->recv[g]) (void)hipFree(mc->recv[g]);
         if (g < (int)mc->comms.size() && mc->comms[g]) mc->rccl.CommDestroy(mc->comms[g]);
     }
+    for (int g = 0; g < (int)mc->twin.size(); g++) {
+        if (!mc->twin[g]) continue;
+        (void)hipSetDevice(mc->twin[g]->device);
+        if (g < (int)mc->ev_fork.size() && mc->ev_fork[g]) (void)hipEventDestroy(mc->ev_fork[g]);
+        if (g < (int)mc->ev_join.size() && mc->ev_join[g]) (void)hipEventDestroy(mc->ev_join[g]);
+        free_model(mc->twin[g]);
+    }
     for (int g = 1; g < mc->G; g++) free_model(mc->rep[g]);
     delete mc;
 }
+
+namespace {
+// every replica stream idle (error paths: the caller may free staging those streams still read — ADVICE r3)
+bool multi_sync_all(MultiCtx * mc) {
+    bool ok = true;
+    for (int g = 0; g < mc->G; g++) {
+        (void)hipSetDevice(mc->rep[g]->device);
+        ok = hipStreamSynchronize(mc->rep[g]->stream) == hipSuccess && ok;
+        if (g < (int)mc->twin.size() && mc->twin[g]) ok = hipStreamSynchronize(mc->twin[g]->stream) == hipSuccess && ok;
+    }
+    return ok;
+}
+}  // namespace
 
 int multi_device_count(const clip_ctx * primary) { return primary && primary->multi ? ((MultiCtx *)primary->multi)->G : 1; }
 
@@ -478,7 +502,13 @@ bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char 
         if (h > l && !run(g, c, l, h, mc->send[g])) okv[g] = 0;
     };
     mc->replicas.run(G, work);
-    for (int g = 0; g < G; g++) if (!okv[g]) { fprintf(stderr, "%s: shard %d failed\n", who, g); return false; }
+    for (int g = 0; g < G; g++)
+        if (!okv[g]) {
+            fprintf(stderr, "%s: shard %d failed\n", who, g);
+            (void)multi_sync_all(mc);            // the other shards' streams may still read the caller's staging
+            (void)hipSetDevice(primary->device);
+            return false;
+        }
     bool ok = true;
     if (mc->collective && mc->use_rccl) {
         // ONE all-gather of the final embeddings: [per_dev][proj] per device -> [G * per_dev][proj] on every device
@@ -486,7 +516,12 @@ bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char 
         for (int g = 0; g < G && ok; g++)
             ok = mc->rccl.AllGather(mc->send[g], mc->recv[g], (size_t)per_dev * proj, kNcclFloat, mc->comms[g], mc->rep[g]->stream) == 0;
         ok = (mc->rccl.GroupEnd() == 0) && ok;
-        if (!ok) { fprintf(stderr, "%s: ncclAllGather failed\n", who); return false; }
+        if (!ok) {
+            fprintf(stderr, "%s: ncclAllGather failed\n", who);
+            (void)multi_sync_all(mc);
+            (void)hipSetDevice(primary->device);
+            return false;
+        }
         (void)hipSetDevice(primary->device);
         // shards are contiguous and only the LAST non-empty one can be short, so the first `total` rows of the gathered buffer are the result
         if (vec) ok = hipMemcpyAsync(vec, mc->recv[0], (size_t)total * proj * 4, hipMemcpyDeviceToHost, primary->stream) == hipSuccess;
@@ -506,6 +541,83 @@ bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char 
             ok = hipStreamSynchronize(mc->rep[g]->stream) == hipSuccess && ok;
         }
     }
+    (void)hipSetDevice(primary->device);
+    return ok;
+}
+
+// Both towers of a step on a multi context: `n_img` images and `n_txt` texts, each in contiguous shards of ceil(n / G); on device g the
+// vision tower runs on replica g's stream and the text tower on the stream of a twin context of the same device, forked and joined with
+// events (the form bench.py's one-process-per-GPU path uses on each rank), then ONE grouped all-gather of [per_img + per_txt][proj] rows
+// per device.  Gathered layout on every device: G blocks of (per_img image rows, per_txt text rows).  Returns synchronised.
+bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * vec_img, float * vec_txt, const char * who,
+                    const std::function<bool(int, clip_ctx *, int, int, float *)> & run_img,
+                    const std::function<bool(int, clip_ctx *, int, int, float *)> & run_txt) {
+    MultiCtx * mc = (MultiCtx *)primary->multi;
+    const int G = mc->G;
+    int per_i = 0, per_t = 0, lo = 0, hi = 0;
+    multi_shard(n_img, G, 0, &lo, &hi, &per_i);
+    multi_shard(n_txt, G, 0, &lo, &hi, &per_t);
+    const int per_dev = per_i + per_t;
+    if ((int)mc->twin.size() != G) { mc->twin.assign(G, nullptr); mc->ev_fork.assign(G, nullptr); mc->ev_join.assign(G, nullptr); }
+    std::vector<char> okv(G, 1);
+    auto work = [&](int g) {
+        clip_ctx * c = mc->rep[g];
+        (void)hipSetDevice(c->device);
+        if (!mc->twin[g]) {
+            mc->twin[g] = load_model(primary->path.c_str(), 0, c->device);
+            if (!mc->twin[g] || hipEventCreateWithFlags(&mc->ev_fork[g], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&mc->ev_join[g], hipEventDisableTiming) != hipSuccess) { okv[g] = 0; return; }
+            (void)hipSetDevice(c->device);
+        }
+        clip_ctx * t = mc->twin[g];
+        void * sp = mc->send[g], * rp = mc->recv[g];
+        size_t sb = mc->send_floats[g] * 4, rb = mc->recv_floats[g] * 4;
+        const bool grew = sb < (size_t)per_dev * proj * 4 || rb < (size_t)G * per_dev * proj * 4;
+        if (grew) (void)hipStreamSynchronize(c->stream);
+        if (!grow_device(sp, sb, (size_t)per_dev * proj * 4) || !grow_device(rp, rb, (size_t)G * per_dev * proj * 4)) { okv[g] = 0; return; }
+        mc->send[g] = (float *)sp; mc->recv[g] = (float *)rp; mc->send_floats[g] = sb / 4; mc->recv_floats[g] = rb / 4;
+        int li, hi_, lt, ht, pd;
+        multi_shard(n_img, G, g, &li, &hi_, &pd);
+        multi_shard(n_txt, G, g, &lt, &ht, &pd);
+        float * s_img = mc->send[g], * s_txt = mc->send[g] + (size_t)per_i * proj;
+        if (hi_ - li < per_i) (void)hipMemsetAsync(s_img + (size_t)(hi_ - li) * proj, 0, (size_t)(per_i - (hi_ - li)) * proj * 4, c->stream);
+        if (ht - lt < per_t) (void)hipMemsetAsync(s_txt + (size_t)(ht - lt) * proj, 0, (size_t)(per_t - (ht - lt)) * proj * 4, c->stream);
+        // fork: the text tower of this call starts with the vision tower, behind whatever the replica stream still holds
+        if (hipEventRecord(mc->ev_fork[g], c->stream) != hipSuccess || hipStreamWaitEvent(t->stream, mc->ev_fork[g], 0) != hipSuccess) { okv[g] = 0; return; }
+        if (hi_ > li && !run_img(g, c, li, hi_, s_img)) okv[g] = 0;
+        if (ht > lt && !run_txt(g, t, lt, ht, s_txt)) okv[g] = 0;
+        // join: the all-gather on the replica stream sees both towers
+        if (hipEventRecord(mc->ev_join[g], t->stream) != hipSuccess || hipStreamWaitEvent(c->stream, mc->ev_join[g], 0) != hipSuccess) okv[g] = 0;
+    };
+    mc->replicas.run(G, work);
+    for (int g = 0; g < G; g++)
+        if (!okv[g]) {
+            fprintf(stderr, "%s: shard %d failed\n", who, g);
+            (void)multi_sync_all(mc);
+            (void)hipSetDevice(primary->device);
+            return false;
+        }
+    bool ok = true;
+    const bool gathered = mc->collective && mc->use_rccl;
+    if (gathered) {
+        ok = mc->rccl.GroupStart() == 0;
+        for (int g = 0; g < G && ok; g++)
+            ok = mc->rccl.AllGather(mc->send[g], mc->recv[g], (size_t)per_dev * proj, kNcclFloat, mc->comms[g], mc->rep[g]->stream) == 0;
+        ok = (mc->rccl.GroupEnd() == 0) && ok;
+        if (!ok) fprintf(stderr, "%s: ncclAllGather failed\n", who);
+    }
+    for (int g = 0; g < G && ok; g++) {
+        // host copies: out of device 0's gathered buffer (block g) after the collective, else out of each replica's send buffer
+        int li, hi_, lt, ht, pd;
+        multi_shard(n_img, G, g, &li, &hi_, &pd);
+        multi_shard(n_txt, G, g, &lt, &ht, &pd);
+        clip_ctx * src_ctx = gathered ? primary : mc->rep[g];
+        const float * blk = gathered ? mc->recv[0] + (size_t)g * per_dev * proj : mc->send[g];
+        (void)hipSetDevice(src_ctx->device);
+        if (vec_img && hi_ > li) ok = hipMemcpyAsync(vec_img + (size_t)li * proj, blk, (size_t)(hi_ - li) * proj * 4, hipMemcpyDeviceToHost, src_ctx->stream) == hipSuccess && ok;
+        if (vec_txt && ht > lt) ok = hipMemcpyAsync(vec_txt + (size_t)lt * proj, blk + (size_t)per_i * proj, (size_t)(ht - lt) * proj * 4, hipMemcpyDeviceToHost, src_ctx->stream) == hipSuccess && ok;
+    }
+    ok = multi_sync_all(mc) && ok;
     (void)hipSetDevice(primary->device);
     return ok;
 }

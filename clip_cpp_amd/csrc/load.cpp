@@ -332,9 +332,14 @@ struct WeightCache {
     }
     void write_image(const std::vector<uint8_t> & buf) const {   // best effort; written to a temporary name and renamed into place
         if (!enabled) return;
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        FILE * f = fopen(tmp.c_str(), "wb");
-        if (!f) return;
+        // one temporary file PER WRITER: clip_amd_model_load_multi loads its G replicas on concurrent threads of one process,
+        // and a name built from the pid alone had them all truncate and fill the same inode while the first finisher renamed it into
+        // place (a published image with zero-filled holes).  mkstemp gives every thread / process its own file; rename stays atomic.
+        std::string tmp = path + ".tmp.XXXXXX";
+        const int fd = mkstemp(&tmp[0]);
+        if (fd < 0) return;
+        FILE * f = fdopen(fd, "wb");
+        if (!f) { (void)close(fd); (void)remove(tmp.c_str()); return; }
         Header hd;
         memcpy(hd.magic, "CLAMDHBM", 8);
         hd.version = kVersion; hd.plan_hash = plan_hash; hd.key = key; hd.image_bytes = buf.size();

@@ -199,6 +199,9 @@ bool multi_image_batch_encode(clip_ctx * primary, const clip_image_f32 * imgs, i
 // generic sharded call: run(g, ctx_g, lo, hi, d_send) queues the work of items [lo, hi) on replica g; see host_pipeline.cpp
 bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char * who,
                const std::function<bool(int, clip_ctx *, int, int, float *)> & run);
+bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * vec_img, float * vec_txt, const char * who,
+                    const std::function<bool(int, clip_ctx *, int, int, float *)> & run_img,
+                    const std::function<bool(int, clip_ctx *, int, int, float *)> & run_txt);
 clip_ctx * multi_replica(const clip_ctx * primary, int g);
 const float * multi_gathered(const clip_ctx * primary, int g);
 

@@ -6,7 +6,7 @@
 // piece up greedily (longest prefix first) in the vocabulary — it is NOT byte-pair merging, does not
 // lower-case, and hard-codes BOS 49406 / EOS 49407.  This file implements the same
 // function with a hand-written scanner (std::regex costs ~100x more per call); equivalence with the
-// regex is fuzz-tested in tests/test_tokenizer.py against the oracle's std::regex restatement.
+// regex is fuzz-tested in tests/test_host_api.py (test_tokenizer_*) against the oracle's std::regex restatement.
 #include <cstdio>
 #include <string>
 

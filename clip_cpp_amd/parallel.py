@@ -13,10 +13,11 @@ import torch.distributed as dist
 
 
 def shard_bounds(total, rank, world):
-    """Contiguous shard [lo, hi) of `total` items for `rank`; sizes differ by at most one, larger shards first."""
-    base, rem = divmod(total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous shard [lo, hi) of `total` items for `rank`: shards of ceil(total / world), trailing shards short or empty — ONE rule for
+    both multi-GPU forms: this is clip_amd_shard_bounds (csrc/host_pipeline.cpp::multi_shard, SURVEY 8e `B_g = ceil(B / G)`) restated in
+    Python so that the per-process form needs no library call; tests/test_parallel_gloo.py holds the two against each other."""
+    per = -(-total // world) if world > 0 else 0
+    return min(total, rank * per), min(total, (rank + 1) * per)
 
 
 def all_gather_rows(local, total_rows, group=None):

@@ -23,7 +23,7 @@ S = clip.vision_config["image_size"]
 
 
 def host_path(threads):
-    keep, arr = clip._u8_array(images)
+    keep, arr, _n = clip._u8_array(images)
     src = cc.ClipImageU8Batch(C.cast(arr, C.POINTER(cc.ClipImageU8)), n)
     out_arr = (cc.ClipImageF32 * n)()
     dst = cc.ClipImageF32Batch(C.cast(out_arr, C.POINTER(cc.ClipImageF32)), n)

@@ -154,5 +154,24 @@ def test_sharded_u8_text_and_device_resident_entry_points(clip_lib, fixture_cach
     out_t = np.empty((40, 32), dtype=np.float32)
     multi.encode_texts_device_multi([t.data_ptr() for t in tk], offs, True, out_t)
     assert np.array_equal(out_t, single.encode_texts(texts))
+    # both towers of a step in one call: vision on the replica stream, text on the twin context's stream, one all-gather (bench.py --single-process)
+    for rep in range(2):     # second round: the twin contexts exist, buffers are warm
+        out_i2, out_t2 = np.zeros((B, 32), dtype=np.float32), np.zeros((40, 32), dtype=np.float32)
+        multi.encode_pair_device_multi(ptrs, B, [t.data_ptr() for t in tk], offs, True, out_i2, out_t2)
+        assert np.array_equal(out_i2, want) and np.array_equal(out_t2, out_t)
+    if ndev >= G and G > 1 or os.environ.get("CLIP_AMD_MULTI_FORCE_RCCL") == "1":
+        # gathered layout of the pair call on every device: G blocks of (rows_per_device(B) image rows, rows_per_device(40) text rows)
+        import ctypes as C
+        per_i, per_t = clip_lib.shard_bounds(B, G, 0)[2], clip_lib.shard_bounds(40, G, 0)[2]
+        for g in range(G):
+            ptr = clip_lib.lib().clip_amd_gathered_embeddings(multi.ctx, g)
+            with torch.cuda.device(g):
+                t = torch.empty((G * (per_i + per_t), 32), dtype=torch.float32, device="cuda:%d" % g)
+                assert C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), t.numel() * 4, 3) == 0
+                blk = t.cpu().numpy().reshape(G, per_i + per_t, 32)
+            for r in range(G):
+                lo, hi, _ = clip_lib.shard_bounds(B, G, r)
+                lt, ht, _ = clip_lib.shard_bounds(40, G, r)
+                assert np.array_equal(blk[r, :hi - lo], want[lo:hi]) and np.array_equal(blk[r, per_i:per_i + ht - lt], out_t[lt:ht])
     multi.close()
     single.close()

@@ -48,8 +48,17 @@ def test_shard_bounds_cover_batch():
             spans = [shard_bounds(total, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
-            sizes = [b - a for a, b in spans]
-            assert max(sizes) - min(sizes) <= 1
+            per = -(-total // world)
+            assert all(b - a == per for a, b in spans if b < total) and all(0 <= b - a <= per for a, b in spans)
+
+
+def test_shard_bounds_is_the_c_abi_rule(clip_lib):
+    """one partitioning for both multi-GPU forms: parallel.shard_bounds == clip_amd_shard_bounds"""
+    from clip_cpp_amd.parallel import shard_bounds
+    for total in (0, 1, 5, 8, 13, 100, 256, 1023, 1024):
+        for world in (1, 2, 3, 4, 7, 8):
+            for r in range(world):
+                assert shard_bounds(total, r, world) == clip_lib.shard_bounds(total, world, r)[:2], (total, world, r)
 
 
 @pytest.mark.parametrize("B", [5, 8, 1])
