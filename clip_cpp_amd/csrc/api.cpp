@@ -722,6 +722,18 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
     (void)hipMemcpy(dg.p, gamma, (size_t)h * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dbeta.p, beta, (size_t)h * 4, hipMemcpyHostToDevice);
     (void)hipMemset(dxn.p, 0, (size_t)(M + 1) * W2.Kpad * 2);
+    // fold == 2: the centred form (GemmParams::xg_mu / ln_mu): the offsets are the row means of the INCOMING residual rows — what the
+    // previous LayerNorm's consumer leaves in the layer chain — computed here in double
+    DBuf dmu((size_t)M * 4), dmu2((size_t)M * 4);
+    if (fold == 2) {
+        std::vector<float> mu((size_t)M);
+        for (int64_t m = 0; m < M; m++) {
+            double sacc = 0;
+            for (int64_t k = 0; k < h; k++) sacc += resid[m * h + k];
+            mu[(size_t)m] = (float)(sacc / (double)h);
+        }
+        (void)hipMemcpy(dmu.p, mu.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+    }
     launch_f32_to_f16((const float *)da32.p, (int)K1, (half_t *)da16.p, W1.Kpad, (int)M, (int)K1, W1.Kpad, s);
     DBuf skw((size_t)64 << 20), skc(4096 * 4);
     (void)hipMemset(skc.p, 0, 4096 * 4);
@@ -751,6 +763,7 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
             a1.xg_out = (half_t *)dxn.p; a1.ldxg = W2.Kpad; a1.xg_gamma = (const float *)dg.p; a1.fstats_out = (float2 *)dstats.p; a1.fstride_out = st_stride;
             a2.A16 = (const half_t *)dxn.p; a2.lda = W2.Kpad; a2.bias = (const float *)dbf.p; a2.ln_c = (const float *)dc.p;
             a2.fstats = (const float2 *)dstats.p; a2.fslots = (int)h / 16; a2.fslotw = 16; a2.fstride = st_stride;
+            if (fold == 2) { a1.xg_mu = (const float *)dmu.p; a2.ln_mu = (const float *)dmu.p; a2.mu_out = (float *)dmu2.p; }
         } else {
             a1.stats_out = (float2 *)dskst.p;
             a2.x32 = (const float *)dx.p; a2.ldx = (int)h; a2.ln_w = (const float *)dg.p; a2.ln_b = (const float *)dbeta.p; a2.stats_in = (const float2 *)dskst.p;
@@ -777,9 +790,11 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
         p1.xg_out = (half_t *)dxn.p; p1.ldxg = W2.Kpad; p1.xg_gamma = (const float *)dg.p; p1.stats_out = (float2 *)dstats.p; p1.stats_stride = st_stride;
         int t1 = tile1 ? tile1 : gemm_tile_for((int)M, (int)h, W1.Kpad, W1.wtype != W_F16);
         const int slotw = gemm_fold_slotw(t1);
+        if (fold == 2) p1.xg_mu = (const float *)dmu.p;
         launch_gemm(p1, EPI_RESID_F32, tile1, s);
         p2.bias = (const float *)dbf.p; p2.ln_c = (const float *)dc.p; p2.ln_stats = (const float2 *)dstats.p; p2.ln_slotw = slotw; p2.ln_slots = (int)h / slotw;
         p2.ln_stride = st_stride; p2.ln_eps = eps;
+        if (fold == 2) { p1.xg_mu = (const float *)dmu.p; p2.ln_mu = (const float *)dmu.p; p2.mu_out = (float *)dmu2.p; }
         launch_gemm(p2, epi, tile2, s);
     } else {
         launch_gemm(p1, EPI_RESID_F32, tile1, s);

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <utility>
 
 #include "model.h"
 
@@ -222,17 +223,22 @@ bool run_layers_skinny(clip_ctx * ctx, const DevTower & tw, int rows, int h, int
 // the 6-7 us these two kernels live.  Precondition as run_layers_fold: xn and ONE statistics slot per row from the entry kernel.
 bool run_layers_skinny_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
                             const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid,
-                            float2 * stats, int stats_stride) {
+                            float2 * stats, int stats_stride, float * mu) {
     hipStream_t s = ctx->stream;
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
     int slots = 1, slotw = h;
+    // centring offsets (kernels.h GemmParams::xg_mu): two [stats_stride] buffers; every consumer reads the one its operand was centred on
+    // and leaves its own row means in the other, which the next producer centres on.  mu == null: the uncentred form.
+    float * mu_cur = mu, * mu_alt = mu ? mu + stats_stride : nullptr;
     auto consume = [&](SkinnyParams & p, const float * c, const float * bf) {
         p.A16 = xn; p.lda = h; p.bias = bf; p.ln_c = c; p.fstats = stats; p.fslots = slots; p.fslotw = slotw; p.fstride = stats_stride; p.eps = eps;
+        if (mu) { p.ln_mu = mu_cur; p.mu_out = mu_alt; std::swap(mu_cur, mu_alt); }
     };
     auto produce = [&](SkinnyParams & p, const float * gamma_next) {
         if (!gamma_next) return;
+        p.xg_mu = mu_cur;
         p.xg_out = xn; p.ldxg = h; p.xg_gamma = gamma_next; p.fstats_out = stats; p.fstride_out = stats_stride;
         slots = h / 16; slotw = 16;
     };
@@ -314,17 +320,20 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
 // Precondition: xn = fp16(x * ln1_w of layer 0) and stats = ONE slot per row over all h columns (launch_layernorm_prep / launch_text_embed).
 bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
                      const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid,
-                     float2 * stats, int stats_stride) {
+                     float2 * stats, int stats_stride, float * mu) {
     hipStream_t s = ctx->stream;
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
     int slots = 1, slotw = h;
+    float * mu_cur = mu, * mu_alt = mu ? mu + stats_stride : nullptr;      // centring offsets, as run_layers_skinny_fold
     auto consume = [&](GemmParams & p, const float * c, const float * bf) {
         p.A = xn; p.lda = h; p.bias = bf; p.ln_c = c; p.ln_stats = stats; p.ln_slots = slots; p.ln_slotw = slotw; p.ln_stride = stats_stride; p.ln_eps = eps;
+        if (mu) { p.ln_mu = mu_cur; p.mu_out = mu_alt; std::swap(mu_cur, mu_alt); }
     };
     auto produce = [&](GemmParams & p, const float * gamma_next) {
         if (!gamma_next) return;                              // last layer: the pooled rows go through the post-LN launch
+        p.xg_mu = mu_cur;
         p.xg_out = xn; p.ldxg = h; p.xg_gamma = gamma_next; p.stats_out = stats; p.stats_stride = stats_stride;
         const bool quant = !p.w16_pre && p.W.wtype != W_F16;
         slotw = gemm_fold_slotw_for(p.M, p.W.N, p.W.Kpad, quant);
@@ -530,6 +539,7 @@ bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st) {
     st.st_stride = (rows + 63) & ~63;                      // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
     auto carve = [&](Carver & c) {
         st.stats = c.take<float2>((size_t)(h / 16) * st.st_stride);
+        st.mu = c.take<float>((size_t)2 * st.st_stride);      // centring offsets of the folded LayerNorms (two buffers, ping-pong)
         st.x = c.take<float>((size_t)rows * h);
         st.xn = c.take<half_t>((size_t)rows * h);
         st.qkv = c.take<half_t>((size_t)rows * 3 * h);
@@ -582,16 +592,16 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
     {
         ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
         if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
-            launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, st.xn, h, st.stats, s);
+            launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, st.xn, h, st.stats, s, ctx->ln_fold_centre ? st.mu : nullptr);
         else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
     }
     if (skinny && fold) {
-        if (!run_layers_skinny_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride)) return false;
+        if (!run_layers_skinny_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr)) return false;
     } else if (skinny) {
         launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
         if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.qkv, st.att, st.mid)) return false;
     } else if (fold) {
-        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride)) return false;
+        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr)) return false;
     } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid)) return false;
     // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
     launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
@@ -657,9 +667,11 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     }
     const int st_stride = (rows + 63) & ~63;                   // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
     float2 * stats = nullptr;
+    float * mu = nullptr;                                      // centring offsets of the folded LayerNorms: [2][st_stride]
     auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& pooled,
                      float *& emb, int *& seq, int *& last) {
         stats = c.take<float2>((size_t)(h / 16) * st_stride);
+        mu = c.take<float>((size_t)2 * st_stride);
         x = c.take<float>((size_t)rows * h);
         xn = c.take<half_t>((size_t)rows * h);
         qkv = c.take<half_t>((size_t)rows * 3 * h);
@@ -751,15 +763,15 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
         const bool fold = ctx->ln_fold && !Tw.layers.empty() && (ctx->ln_fold_force || fold_pays(Tw, rows));
         if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
-            launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats);
+            launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats, ctx->ln_fold_centre ? mu : nullptr);
         else launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
         if (skinny && fold) {
-            if (!run_layers_skinny_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride)) return false;
+            if (!run_layers_skinny_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride, ctx->ln_fold_centre ? mu : nullptr)) return false;
         } else if (skinny) {
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, qkv, att, mid)) return false;
         } else if (fold) {
-            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride)) return false;
+            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride, ctx->ln_fold_centre ? mu : nullptr)) return false;
         } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
         // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
         launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);

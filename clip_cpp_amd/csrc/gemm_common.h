@@ -231,6 +231,16 @@ __device__ __forceinline__ float2 ln_row_final(const GemmParams & p, int m) {
     return make_float2(mean, 1.0f / sqrtf(m2 * invh + p.ln_eps));
 }
 
+// ln_row_final + the centring of the operand (GemmParams::ln_mu / mu_out): the epilogue's "mean" becomes mean - mu_m, and the workgroups
+// of the first column tile (`writer`) leave the true mean for the next producer.  Rows past M arrive clamped to M - 1 (same value).
+__device__ __forceinline__ float2 ln_row_centred(const GemmParams & p, int m, bool writer) {
+    const float mu = p.ln_mu ? p.ln_mu[m] : 0.f;          // in flight with the statistics loads
+    float2 r = ln_row_final(p, m);
+    if (writer && p.mu_out) p.mu_out[m] = r.x;
+    r.x -= mu;
+    return r;
+}
+
 // Consumer, after the K loop: thread t < BM parks its row's (mean, rstd) in LDS (the tile buffers are idle: the caller's barrier
 // `sync` separates the last fragment reads from these writes); the epilogues read the TM rows of a lane's accumulators from there
 // (ln_rows_read).  rs: LDS area of BM float2 that does not overlap the fp16 staging areas of the epilogue.
@@ -261,6 +271,12 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
     static_assert(TN % SA == 0, "a wave's columns are whole statistics slots");
     const int N = p.W.N;
     const bool staged = SA == 4 && stage != nullptr && (p.ldxg & 7) == 0;
+    // centring offset of row m (0 = the uncentred form: same bits as r03).  Fetched per row right where it is used — an L1 / L2 hit after the
+    // first slot — instead of TM values held across the tail: the 192-row tile has no registers left for them (it spilled with an array)
+    auto mu_of = [&](int b) {
+        const int m = mbase + b * 16 + frow;
+        return p.xg_mu ? p.xg_mu[m < p.M ? m : p.M - 1] : 0.f;
+    };
     // one statistics slot (SA strips) at a time: its gamma values, its statistics, its xg columns (a 128 x 128 wave sub-tile of
     // k_gemm4.hip would otherwise hold 8 strips of gamma beside its accumulators)
 #pragma unroll
@@ -302,14 +318,16 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
                 constexpr int RS = 68;
                 const int rrow = lane >> 3, rchunk = lane & 7;
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                for (int b = 0; b < TM; b++) {
+                    const float mub = mu_of(b);
 #pragma unroll
-                    for (int b = 0; b < TM; b++) {
-                        const f4 g = acc[sp * 4 + a][b] * gam[a];
+                    for (int a = 0; a < 4; a++) {
+                        const f4 g = (acc[sp * 4 + a][b] - mub) * gam[a];
                         const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]};
                         const h2 hi = (h2){(_Float16)g[2], (_Float16)g[3]};
                         *(uint2 *)(stage + (b * 16 + frow) * RS + a * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
                     }
+                }
 #pragma unroll
                 for (int i = 0; i < TM * 2; i++) {
                     const int ml = i * 8 + rrow;
@@ -321,16 +339,18 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
             }
         }
 #pragma unroll
-        for (int i = 0; i < SA; i++)
+        for (int b = 0; b < TM; b++) {
+            const int m = mbase + b * 16 + frow;
+            if (m >= p.M) continue;
+            const float mub = mu_of(b);
 #pragma unroll
-            for (int b = 0; b < TM; b++) {
-                const int m = mbase + b * 16 + frow;
-                if (m >= p.M) continue;
-                const f4 g = acc[sp * SA + i][b] * gam[i];
+            for (int i = 0; i < SA; i++) {
+                const f4 g = (acc[sp * SA + i][b] - mub) * gam[i];
                 const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]};
                 const h2 hi = (h2){(_Float16)g[2], (_Float16)g[3]};
                 *(uint2 *)(p.xg_out + (size_t)m * p.ldxg + n + i * 16 + fgrp * 4) = make_uint2(h2u(lo), h2u(hi));
             }
+        }
     }
 }
 

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
     const bool ln = LNE && p.ln_c != nullptr;
     float2 ln_mine = make_float2(0.f, 1.f);
     if constexpr (LNE) {
-        if (ln && tid < BM) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
+        if (ln && tid < BM) ln_mine = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, tile_n == 0 && split == 0);
     }
     STORE_B(B0, 0);
     __syncthreads();
@@ -296,6 +296,17 @@ __global__ void __launch_bounds__(NTHREADS, ((BM + BN) * BK * 4 <= 80 * 1024 ? 2
 #undef COMPUTE
 #undef COMPUTE_SCHED
     asm volatile("" ::: "memory");
+#ifdef CLIPAMD_ABLATION   // p.debug bit 3: the K loop alone — no epilogue (the never-true store keeps the accumulators alive)
+    if (p.debug & 8) {
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; a++)
+#pragma unroll
+            for (int b = 0; b < TM; b++) keep += (acc[a][b][0] + acc[a][b][1]) + (acc[a][b][2] + acc[a][b][3]);
+        if (keep == 1.2345e33f) ((float *)p.out)[tid] = keep;
+        return;
+    }
+#endif
     if constexpr (SK) {
         if (ksplit > 1) {
             // Deterministic split-K fix-up: every workgroup parks its partial tile in the workspace ([tile][split][frag][thread]
@@ -554,6 +565,9 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
             if (p.resid) rest.resid = p.resid + (size_t)m1 * p.ldc;
             // LayerNorm fold: the statistics are [slot][row] (row offset = pointer offset), xg is row-major
             if (p.ln_stats) rest.ln_stats = p.ln_stats + m1;
+            if (p.ln_mu) rest.ln_mu = p.ln_mu + m1;
+            if (p.mu_out) rest.mu_out = p.mu_out + m1;
+            if (p.xg_mu) rest.xg_mu = p.xg_mu + m1;
             if (p.stats_out) rest.stats_out = p.stats_out + m1;
             if (p.xg_out) rest.xg_out = p.xg_out + (size_t)m1 * p.ldxg;
             launch_gemm(head, epilogue, tile, stream);

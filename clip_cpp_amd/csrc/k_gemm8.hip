@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
     const bool ln = LNE && p.ln_c != nullptr;
     float2 ln_mine = make_float2(0.f, 1.f);
     if constexpr (LNE) {
-        if (ln && tid < BM) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
+        if (ln && tid < BM) ln_mine = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, n0 == 0);
         __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): said with the builtin so that hipcc's own counting restarts from zero
     }
     ISSUE_W(0, 0);

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
                 n = n < p.W.N ? n : 0;
                 c_pre[a] = *(const f4 *)(p.ln_c + n);
             }
-            if (tid < RBM) ln_mine = ln_row_final(p, m0 + tid < p.M ? m0 + tid : p.M - 1);
+            if (tid < RBM) ln_mine = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, n0 == 0 && split == 0);
         }
     }
     int st = 0;                // stage of tile kt
@@ -384,6 +384,17 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) gemm_ring_kernel(con
 #undef RING_RAW
 #undef RING_WAIT
     asm volatile("" ::: "memory");
+#ifdef CLIPAMD_ABLATION   // p.debug bit 3: the K loop alone — no epilogue (the never-true store keeps the accumulators alive)
+    if (p.debug & 8) {
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; a++)
+#pragma unroll
+            for (int b = 0; b < TM; b++) keep += (acc[a][b][0] + acc[a][b][1]) + (acc[a][b][2] + acc[a][b][3]);
+        if (keep == 1.2345e33f) ((float *)p.out)[tid] = keep;
+        return;
+    }
+#endif
 
     if (ksplit > 1) {
         // deterministic split-K fix-up, as in k_gemm.hip: partials parked with agent-scope (write-through) stores, per-tile ticket,

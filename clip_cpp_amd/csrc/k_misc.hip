@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float * __restrict
 // squared deviations from the mean) of y as ONE slot of width h.  The row lives in registers: every pass is a register pass.
 template <int NV>
 __device__ __forceinline__ void row_fold_prep(const f4 (&y)[NV], int h, int lane, const float * __restrict__ gnext, half_t * __restrict__ xg_row,
-                                              float2 * __restrict__ stat) {
+                                              float2 * __restrict__ stat, float * __restrict__ mu_row) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; i++)
@@ -105,11 +105,14 @@ __device__ __forceinline__ void row_fold_prep(const f4 (&y)[NV], int h, int lane
         }
     q = wave_sum(q);
     if (lane == 0) *stat = make_float2(s, q);
+    // centred form (GemmParams::ln_mu): the operand is built about the row's own mean, which the first consumer gets as its offset
+    const float off = mu_row ? mean : 0.f;
+    if (mu_row && lane == 0) *mu_row = mean;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * 4;
         if (c < h) {
-            const f4 g = y[i] * *(const f4 *)(gnext + c);
+            const f4 g = (y[i] - off) * *(const f4 *)(gnext + c);
             const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]}, hi = (h2){(_Float16)g[2], (_Float16)g[3]};
             *(uint2 *)(xg_row + c) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
         }
@@ -120,7 +123,7 @@ template <int NV>
 __global__ void __launch_bounds__(256) layernorm_prep_kernel(const float * x, int ldx, const float * __restrict__ w, const float * __restrict__ b,
                                                              float eps, int rows, int h, float * out32, int ld32,
                                                              const float * __restrict__ gnext, half_t * __restrict__ xg, int ldxg,
-                                                             float2 * __restrict__ stats) {
+                                                             float2 * __restrict__ stats, float * __restrict__ mu_out) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) layernorm_prep_kernel(const float * x, in
             }
         }
     }
-    row_fold_prep<NV>(v, h, lane, gnext, xg + (size_t)r * ldxg, stats + r);
+    row_fold_prep<NV>(v, h, lane, gnext, xg + (size_t)r * ldxg, stats + r, mu_out ? mu_out + r : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restr
                                                          const uint8_t * __restrict__ tok, int tok_type, size_t tok_row_bytes,
                                                          const float * __restrict__ pos, int h, float * __restrict__ x,
                                                          const float * __restrict__ gnext, half_t * __restrict__ xg, int ldxg,
-                                                         float2 * __restrict__ stats) {
+                                                         float2 * __restrict__ stats, float * __restrict__ mu_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -391,7 +394,7 @@ __global__ void __launch_bounds__(256) text_embed_kernel(const int32_t * __restr
             v[i] = (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    if (gnext) row_fold_prep<NV>(v, h, lane, gnext, xg + (size_t)row * ldxg, stats + row);
+    if (gnext) row_fold_prep<NV>(v, h, lane, gnext, xg + (size_t)row * ldxg, stats + row, mu_out ? mu_out + row : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,12 +545,12 @@ static size_t raw_row_bytes(int type, int k) {
 }
 
 void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw, int tok_type,
-                       const float * pos, int h, float * x, hipStream_t stream, const float * gamma_next, half_t * xg, int ldxg, float2 * stats) {
+                       const float * pos, int h, float * x, hipStream_t stream, const float * gamma_next, half_t * xg, int ldxg, float2 * stats, float * mu_out) {
     if (rows <= 0) return;
     const dim3 grid((rows + 3) / 4), block(256);
 #define CLIPAMD_TE(NV)                                                                                                              \
     hipLaunchKernelGGL((text_embed_kernel<NV>), grid, block, 0, stream, ids, seq_start, nseq, rows, (const uint8_t *)tok_raw, tok_type, \
-                       raw_row_bytes(tok_type, h), pos, h, x, gamma_next, xg, ldxg, stats)
+                       raw_row_bytes(tok_type, h), pos, h, x, gamma_next, xg, ldxg, stats, mu_out)
     if (h <= 256) { CLIPAMD_TE(1); }
     else if (h <= 512) { CLIPAMD_TE(2); }
     else if (h <= 768) { CLIPAMD_TE(3); }
@@ -558,11 +561,11 @@ void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int
 }
 
 void launch_layernorm_prep(const float * x, int ldx, const float * w, const float * b, float eps, int rows, int h, float * out32, int ld32,
-                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream) {
+                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream, float * mu_out) {
     if (rows <= 0) return;
     const dim3 grid((rows + 3) / 4), block(256);
 #define CLIPAMD_LNP(NV)                                                                                                             \
-    hipLaunchKernelGGL((layernorm_prep_kernel<NV>), grid, block, 0, stream, x, ldx, w, b, eps, rows, h, out32, ld32, gamma_next, xg, ldxg, stats)
+    hipLaunchKernelGGL((layernorm_prep_kernel<NV>), grid, block, 0, stream, x, ldx, w, b, eps, rows, h, out32, ld32, gamma_next, xg, ldxg, stats, mu_out)
     if (h <= 256) { CLIPAMD_LNP(1); }
     else if (h <= 512) { CLIPAMD_LNP(2); }
     else if (h <= 768) { CLIPAMD_LNP(3); }

@@ -124,8 +124,10 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
     static_assert(MF <= NW, "each wave finalises at most one fragment row");
     f4 bias_pre = (f4){0.f, 0.f, 0.f, 0.f}, resid_pre = (f4){0.f, 0.f, 0.f, 0.f}, c_pre = (f4){0.f, 0.f, 0.f, 0.f}, gam_pre = (f4){0.f, 0.f, 0.f, 0.f};
     const bool foldc = FOLDC && p.ln_c != nullptr;
+    float mu_pre = 0.f;                                // producer: the offset this lane's new operand row is centred on (SkinnyParams::xg_mu)
     {
         const int n = n0 + fgrp * 4, m = m_base + wave * 16 + frow;
+        if constexpr (EPI == EPI_RESID_F32) { if (p.xg_out && p.xg_mu && wave < MF) mu_pre = p.xg_mu[m < p.M ? m : p.M - 1]; }
         if (EPI != EPI_PATCH_F32 && p.bias && n < p.W.N) bias_pre = *(const f4 *)(p.bias + n);
         if constexpr (FOLDC) { if (foldc && n < p.W.N) c_pre = *(const f4 *)(p.ln_c + n); }
         if constexpr (EPI == EPI_RESID_F32) { if (p.xg_out && n < p.W.N) gam_pre = *(const f4 *)(p.xg_gamma + n); }
@@ -185,6 +187,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
             const int r = tid / TPR, sub = tid % TPR;
             const int gr = m_base + r;
             const float2 * st = p.fstats + (gr < p.M ? gr : p.M - 1);
+            const float mu_in = (sub == 0 && p.ln_mu) ? p.ln_mu[gr < p.M ? gr : p.M - 1] : 0.f;      // offset the operand was centred on
             const float w = (float)p.fslotw, invw = 1.0f / w;
             float n_ = 0.f, mean_ = 0.f, m2_ = 0.f;
             for (int base = 0; base < p.fslots; base += TPR * 8) {
@@ -215,7 +218,10 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
                 m2_ = q0_ + q1_ + (d * d) * (n0_ * n1_ * inv);
                 n_ = nn;
             }
-            if (sub == 0) lnst[r] = make_float2(mean_, 1.0f / sqrtf(m2_ / n_ + p.eps));
+            if (sub == 0) {
+                if (p.mu_out && blockIdx.x == 0 && gr < p.M) p.mu_out[gr] = mean_;       // this LayerNorm's row mean, for the next producer
+                lnst[r] = make_float2(mean_ - mu_in, 1.0f / sqrtf(m2_ / n_ + p.eps));
+            }
         }
     }
     SK_STAMP(2);           // LayerNorm prologue done (statistics round trip + barrier)
@@ -280,7 +286,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
             if (p.xg_out) {      // LayerNorm fold, producer half: the next GEMM's operand fp16(x gamma_next) and the statistics of this
                                  // workgroup's 16 columns (sum, sum of squared deviations from their mean: two passes in registers)
                 if (ok) {
-                    const f4 g = o * gam_pre;
+                    const f4 g = (o - mu_pre) * gam_pre;
                     const h2 glo = (h2){(_Float16)g[0], (_Float16)g[1]}, ghi = (h2){(_Float16)g[2], (_Float16)g[3]};
                     *(uint2 *)(p.xg_out + (size_t)m * p.ldxg + n) = make_uint2(h2u(glo), h2u(ghi));
                 }

@@ -105,6 +105,14 @@ struct GemmParams {
     const float * xg_gamma = nullptr;
     float2 * stats_out = nullptr;
     int stats_stride = 0;
+    // Centring of the folded operand (round 4; the reference normalises FIRST, in f32 with double sums: clip.cpp:1350-1355).  fp16(x gamma)
+    // carries the row's common mode: for a row with |mean| = k sigma its rounding error is ~k times that of fp16(LN(x)).  So the operand
+    // is built about a per-row offset mu_m the producer already knows — the row's mean at the PREVIOUS LayerNorm, which the previous
+    // consumer computed anyway: xg = fp16((x - mu_m) gamma), and the consumer applies rstd (acc - (mean - mu_m) c) + b'.  Exact algebra
+    // for any mu; with mu = mean it IS the unfolded operand up to the 1/sigma scale.  All three null = the uncentred r03 form.
+    const float * xg_mu = nullptr;         // producer: [M] offsets the new operand is centred on
+    const float * ln_mu = nullptr;         // consumer: [M] offsets A was centred on
+    float * mu_out = nullptr;              // consumer: [M], the workgroups of the first column tile leave this LayerNorm's row means here
 };
 
 // tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64 / 65;
@@ -177,6 +185,8 @@ struct SkinnyParams {
     const float * xg_gamma = nullptr;
     float2 * fstats_out = nullptr;
     int fstride_out = 0;
+    const float * xg_mu = nullptr, * ln_mu = nullptr;      // centring of the folded operand: as GemmParams::xg_mu / ln_mu / mu_out
+    float * mu_out = nullptr;
     unsigned long long * stamps = nullptr;   // -DCLIPAMD_SK_TIMING builds (scripts/build_sk_timing.sh): 16 phase stamps of the first and the last workgroup
 };
 constexpr int SKINNY_MAX_ROWS = 512;    // rows the statistics buffers are sized for ([2][SKINNY_MAX_ROWS][stats_cap] float2)
@@ -193,8 +203,9 @@ void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_
 // stream y — xg[r] = fp16(y[r] * gamma_next) and the whole-row statistics stats[r] = (sum, sum of squared deviations): ONE slot of
 // width h (GemmParams::ln_slots = 1, ln_slotw = h).  launch_layernorm_prep: y = LayerNorm(x) w + b (the vision tower's pre-LN,
 // reference clip.cpp:1334-1339) written to out32 in the same launch; launch_text_embed with xg != null: y = the embedded rows.
+// mu_out != null: the centred form — xg = fp16((y - mean) gamma_next), mu_out[r] = mean (GemmParams::ln_mu of the first consumer).
 void launch_layernorm_prep(const float * x, int ldx, const float * w, const float * b, float eps, int rows, int h, float * out32, int ld32,
-                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream);
+                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream, float * mu_out = nullptr);
 
 // Multi-head self-attention softmax(QK^T)V (reference clip.cpp:1382-1388; causal for text :1101).
 // qkv: [rows][3h] fp16 with Q pre-scaled; sequences given by seq_start[nseq+1] (device) or, when
@@ -214,7 +225,7 @@ void launch_cls_rows(float * x, const float * class_embd, const float * pos, int
 void launch_meta_upload(const int * src_mapped, int * seq, int * last, int n_texts, unsigned * done_mapped, unsigned stamp, hipStream_t stream);
 void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int rows, const void * tok_raw,
                        int tok_type, const float * pos, int h, float * x, hipStream_t stream,
-                       const float * gamma_next = nullptr, half_t * xg = nullptr, int ldxg = 0, float2 * stats = nullptr);
+                       const float * gamma_next = nullptr, half_t * xg = nullptr, int ldxg = 0, float2 * stats = nullptr, float * mu_out = nullptr);
 
 // out[r][:] = v[r][:] / ||v[r]||_2  (reference clip.cpp:1446-1455) or plain copy when !normalize
 void launch_l2norm(const float * v, float * out, int rows, int n, bool normalize, hipStream_t stream);

@@ -135,6 +135,7 @@ struct clip_ctx {
     // residual epilogues and read by the LayerNorm-fused projections of the next sub-layer
     float2 * sk_stats = nullptr;
     bool ln_fold_force = false;      // CLIP_AMD_LNFOLD=2
+    bool ln_fold_centre = true;      // the folded operand is built about the row's mean at the previous LayerNorm (kernels.h GemmParams::xg_mu; CLIP_AMD_LNFOLD_CENTRE=0: the r03 form, for A/B)
     bool ln_fold = true;             // LayerNorm folded into the GEMM epilogues for > 64 rows (CLIP_AMD_LNFOLD=0: the two-launch form, for A/B)
     // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
     clipamd::half_t * w16_panel = nullptr;
@@ -177,6 +178,7 @@ struct VisionStage {
     float * x = nullptr, * emb = nullptr;
     half_t * xn = nullptr, * qkv = nullptr, * att = nullptr, * mid = nullptr, * col = nullptr, * pooled = nullptr;
     float2 * stats = nullptr;
+    float * mu = nullptr;
 };
 bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st);
 bool vision_stage_patch(clip_ctx * ctx, const VisionStage & st, const void * imgs, int i0, int n);

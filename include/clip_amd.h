@@ -150,7 +150,9 @@ int clip_amd_test_gemm_ex(int type, const void * w_raw, int64_t N, int64_t K, co
  * fold = 0: three launches (GEMM, LayerNorm kernel, GEMM); fold = 1: two launches — the residual epilogue also writes fp16(x1 gamma) and
  * partial row statistics, the second GEMM's epilogue applies rstd (acc - mean c) + b'.  tile1 / tile2 as `tile` of clip_amd_test_gemm.
  * x1_out [M][h] f32, y_out [M][N2] (fp16 widened).  h % 64 == 0.  tile1 < 0: both GEMMs on the small-M kernels (k_skinny.hip, M <= 128; fold = 0
- * is then the LayerNorm fused on the operand, fold = 1 the folded form). */
+ * is then the LayerNorm fused on the operand, fold = 1 the folded form).  fold = 2: the folded form with the operand CENTRED (the default of
+ * the layer chain since round 4): fp16((x1 - mu) gamma) with mu_m = the mean of row m of `resid` (what the previous LayerNorm's consumer
+ * leaves), and rstd (acc - (mean - mu) c) + b' in the consumer. */
 int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, const void * w2_raw, int64_t N2, const float * a, int64_t M,
                          const float * b1, const float * resid, const float * gamma, const float * beta, float eps, const float * b2,
                          int epi2, int tile1, int tile2, int fold, int qcols, float qscale, float * x1_out, float * y_out);

@@ -1,11 +1,14 @@
 """GPU tier, kernel level: every HIP kernel of the hot path against the oracle / numpy on seeded inputs,
 called through the C ABI test hooks (include/clip_amd.h).  All tests need a real MI355X."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 from oracle import ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -525,7 +528,7 @@ def run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, t
     return x1, y
 
 
-def _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=0.3):
+def _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=0.3, outlier=20.0):
     tid = ref.GGML_TYPES[tname]
     raw1 = ref.quantize(tid, _weights(rng, h, K1))
     W2 = _weights(rng, N2, h)
@@ -533,7 +536,7 @@ def _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=0.3):
     Wd2 = ref.dequantize(tid, raw2, N2, h).astype(np.float64)
     A = rng.standard_normal((M, K1)).astype(np.float32)
     resid = (rng.standard_normal((M, h)) * 2.5 + mean_shift).astype(np.float32)
-    resid[:, rng.integers(0, h, size=2)] *= 20.0            # outlier channels of the residual stream
+    resid[:, rng.integers(0, h, size=2)] *= outlier         # outlier channels of the residual stream
     b1 = (rng.standard_normal(h) * 0.1).astype(np.float32)
     g = (1 + rng.standard_normal(h) * 0.2).astype(np.float32)
     beta = (rng.standard_normal(h) * 0.1).astype(np.float32)
@@ -561,7 +564,8 @@ def _lnfold_reference(x1, g, beta, Wd2, b2, epi2, qcols, qscale, eps=1e-5):
 @pytest.mark.parametrize("tile1,tile2,epi2", [(64064, 64064, 1), (64128, 128064, 2), (128128, 160128, 3), (160128, 192128, 1), (192128, 128128, 2),
                                               (65064, 65128, 1), (65128, 65064, 3), (3065128, 2064064, 2), (160256, 160256, 1), (256259, 256259, 3),
                                               (256256, 128256, 2), (0, 0, 1)])
-def test_lnfold_vs_float64_and_two_launch_form(L, tname, tile1, tile2, epi2):
+@pytest.mark.parametrize("fold", [1, 2])
+def test_lnfold_vs_float64_and_two_launch_form(L, tname, tile1, tile2, epi2, fold):
     """The folded form (residual epilogue emits fp16(x gamma) + partial statistics, consumer epilogue applies rstd (acc - mean c) + b')
     through every producer / consumer kernel: (a) the f32 residual rows are bit-identical to the unfolded launch, (b) the output is within
     the rigorous fp16-operand bound of the float64 LayerNorm + product, (c) folded and three-launch outputs agree to 2 fp16 ulp (99.9 % of the outputs; 3 ulp all)."""
@@ -570,7 +574,7 @@ def test_lnfold_vs_float64_and_two_launch_form(L, tname, tile1, tile2, epi2):
     tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2)
     qc, qs = (128, 0.125) if epi2 == 1 else (0, 1.0)
     x1a, ya = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, tile1, tile2, 0, qc, qs)
-    x1b, yb = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, tile1, tile2, 1, qc, qs)
+    x1b, yb = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, tile1, tile2, fold, qc, qs)     # fold 2: centred operand
     if tile1 // 1000000 <= 1:     # (split-K re-associates the fp32 sums identically in both runs too: same kernel, same order)
         assert np.array_equal(x1a, x1b), _diff_report(x1a, x1b)
     want, bound, lin = _lnfold_reference(x1b, g, beta, Wd2, b2, epi2, qc, qs)
@@ -596,10 +600,11 @@ def test_lnfold_is_bitwise_independent_of_the_producer_and_consumer_kernels(L, t
     rng = np.random.default_rng(11)
     M, h, K1, N2 = 150, 384, 128, 320
     tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2)
-    base = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, 64128, 64128, 1)[1]
-    for t1, t2 in [(64064, 64128), (65064, 64128), (65128, 128128), (160128, 65064), (192128, 65128), (160256, 160128), (256259, 256256), (128064, 128064)]:
-        y = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, t1, t2, 1)[1]
-        assert np.array_equal(base, y), "tiles (%d, %d): %s" % (t1, t2, _diff_report(base, y))
+    for fold in (1, 2):            # 2: the centred operand (per-row offsets): the same invariance
+        base = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, 64128, 64128, fold)[1]
+        for t1, t2 in [(64064, 64128), (65064, 64128), (65128, 128128), (160128, 65064), (192128, 65128), (160256, 160128), (256259, 256256), (128064, 128064)]:
+            y = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, t1, t2, fold)[1]
+            assert np.array_equal(base, y), "fold %d tiles (%d, %d): %s" % (fold, t1, t2, _diff_report(base, y))
 
 
 @pytest.mark.parametrize("tname,M,h,K1,N2,epi2", [("q4_0", 1600, 768, 768, 2304, 1), ("q4_0", 1600, 768, 3072, 3072, 3), ("f16", 1300, 1024, 1024, 3072, 1),
@@ -617,6 +622,37 @@ def test_lnfold_model_shapes_heuristic_tiles(L, tname, M, h, K1, N2, epi2):
     assert bad.size == 0, "%d/%d bad, max err %g" % (len(bad), yb.size, err.max())
     rel = np.linalg.norm(yb - want) / np.linalg.norm(want)
     assert rel < 2e-3, rel
+
+
+@pytest.mark.parametrize("tname,M,h,K1,N2,epi2", [("q4_0", 1600, 768, 768, 2304, 1), ("f16", 1300, 1024, 1024, 4096, 3), ("q4_0", 50, 768, 3072, 3072, 3)])
+def test_lnfold_centred_operand_under_large_row_means(L, tname, M, h, K1, N2, epi2):
+    """VERDICT r3 item 3 / ADVICE r3: rows of the residual stream whose mean is k sigma away from zero, and outlier channels.  The r03 fold
+    multiplied fp16(x gamma): its operand rounding error grows ~k-fold against the reference's normalise-first order (clip.cpp:1350-1355).
+    The centred fold (fold = 2: fp16((x - mu) gamma), mu = the row's mean at the previous LayerNorm) must stay within 2x the error of the
+    three-launch form everywhere in the sweep; the table goes to gpurun_out/ (DESIGN.md section 3 carries it)."""
+    lines = []
+    skinny = M <= 64
+    t1 = -1 if skinny else 0
+    for outlier in (20.0, 100.0):
+        for k in (0, 2, 5, 10, 30):
+            rng = np.random.default_rng(1000 + k + int(outlier))
+            tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=2.5 * k, outlier=outlier)
+            qc, qs = (h, 0.125) if epi2 == 1 else (0, 1.0)
+            rel = {}
+            for fold in (0, 1, 2):
+                x1, y = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, t1, 0, fold, qc, qs)
+                want, bound, lin = _lnfold_reference(x1, g, beta, Wd2, b2, epi2, qc, qs)
+                assert np.all(np.isfinite(y))
+                rel[fold] = float(np.linalg.norm(y - want) / np.linalg.norm(want))
+                if fold == 2:
+                    x64 = x1.astype(np.float64)
+                    ratio = float(np.median(np.abs(x64.mean(1)) / x64.std(1)))
+            lines.append("%-5s M=%-5d h=%-5d outlier x%-4g mean shift %2d sigma (median |mean|/std of the rows %.2f): rel. L2 error vs float64  three-launch %.3e  fold r03 %.3e (x%.1f)  fold centred %.3e (x%.2f)" % (
+                tname, M, h, outlier, k, ratio, rel[0], rel[1], rel[1] / rel[0], rel[2], rel[2] / rel[0]))
+            assert rel[2] <= 2.0 * rel[0] + 2e-5, lines[-1]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04_lnfold_centre_sweep.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
 
 
 # ---- the large-M kernels against float64 AT the sizes they run at (VERDICT r2 weak #2: so far bit-identity to the 64 x 64 tile at
