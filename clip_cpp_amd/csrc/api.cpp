@@ -217,14 +217,15 @@ bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct 
 // raw u8 images -> embeddings with the resize/crop/normalise on the GPU (bit-identical to clip_image_preprocess):
 // ships <= 3 B/pixel of the ORIGINAL image instead of 12 B/pixel of the resized one and takes the double-precision
 // resampling (the dominant host cost of benchmark.cpp / zsl.cpp style callers) off the CPU.
-// n raw images -> d_out [n][proj] on ctx's device, queued on ctx->stream (chunks of <= 256 images / ~512 MB of raw pixels; the host
-// side of a chunk's staging is re-used by the next one, hence the synchronisation between chunks).
+// n raw images -> d_out [n][proj] on ctx's device, queued on ctx->stream (chunks of <= 256 images / ~512 MB of raw pixels; a call of
+// several chunks double-buffers the staging so that chunk c + 1's host copy and H2D run under chunk c's forward pass).
 static bool encode_u8_to_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out, bool normalize) {
     const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
     const size_t per = (size_t)S * S * 3;
     (void)hipSetDevice(ctx->device);
     bool ok = true;
-    int b0 = 0;
+    int b0 = 0, chunk_idx = 0;
+    const bool multi_chunk = n > 256;
     while (b0 < n && ok) {
         int bc = 0;
         size_t bytes = 0;
@@ -236,10 +237,12 @@ static bool encode_u8_to_device(clip_ctx * ctx, const clip_image_u8 * imgs, int 
             fprintf(stderr, "clip_amd_image_batch_encode_u8: out of device memory\n");
             return false;
         }
-        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in);
+        // one chunk: the single staging blob; several: double-buffered staging, no synchronisation between chunks — the host fills the
+        // next chunk's pinned blob and the copy stream ships it under this chunk's forward pass (preprocess.cpp)
+        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in, multi_chunk ? (chunk_idx & 1) : -1);
         ok = ok && vision_forward_device(ctx, (const float *)ctx->io_in, bc, d_out + (size_t)b0 * proj, normalize);
         b0 += bc;
-        if (b0 < n) ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        chunk_idx++;
     }
     return ok;
 }

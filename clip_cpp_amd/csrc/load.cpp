@@ -612,6 +612,7 @@ void free_model(clip_ctx * ctx) {
         if (ctx->io_in) (void)hipFree(ctx->io_in);
         if (ctx->io_out) (void)hipFree(ctx->io_out);
         if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
+        free_preprocess_slots(ctx);
         if (ctx->w16_panel) (void)hipFree(ctx->w16_panel);
         if (ctx->sk_stats) (void)hipFree(ctx->sk_stats);
         if (ctx->sk_ws) (void)hipFree(ctx->sk_ws);

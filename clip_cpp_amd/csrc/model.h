@@ -126,6 +126,11 @@ struct clip_ctx {
     hipEvent_t ev_stream_switch = nullptr;   // orders a new stream behind the work queued on the previous one (clip_amd_set_stream)
     void * pre_buf = nullptr;        // device blob of the GPU preprocessing path (descriptors, taps, raw pixels, row buffer)
     size_t pre_bytes = 0;
+    // ... and its double-buffered form for calls of several chunks (clip_amd_image_batch_encode_u8 > 256 images): while chunk c is
+    // preprocessed and encoded, the host fills slot (c + 1) & 1 and the copy stream ships it (preprocess.cpp)
+    struct PreSlot { void * pin = nullptr; size_t pin_bytes = 0; void * dev = nullptr; size_t dev_bytes = 0; hipEvent_t ev_h2d = nullptr, ev_done = nullptr; bool used = false; };
+    PreSlot pre_slot[2];
+    hipStream_t pre_copy_stream = nullptr;
     // split-K workspace of the GEMM (kernels.h GemmParams::sk_*): partial tiles + per-tile ticket counters (kept zero)
     float * sk_ws = nullptr;
     size_t sk_ws_floats = 0;
@@ -210,7 +215,8 @@ const float * multi_gathered(const clip_ctx * primary, int g);
 // host pieces
 bool tokenize_text(const clip_ctx * ctx, const char * text, std::vector<int32_t> & out);            // tokenizer.cpp
 bool preprocess_image(const clip_ctx * ctx, const clip_image_u8 * img, clip_image_f32 * res);      // preprocess.cpp
-bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out);     // preprocess.cpp + k_preproc.hip
+bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out, int slot = -1);   // preprocess.cpp + k_preproc.hip; slot 0 / 1: pipelined staging
+void free_preprocess_slots(clip_ctx * ctx);
 bool load_image_file(const char * fname, clip_image_u8 * img);                                      // image_io.cpp
 
 // quant.cpp — host codecs for the ggml block formats

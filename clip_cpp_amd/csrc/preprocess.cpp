@@ -140,7 +140,24 @@ bool preprocess_image(const clip_ctx * ctx, const clip_image_u8 * img, clip_imag
 // tables (one per distinct (source size, target size) pair), packs {descriptors, tables, raw u8 pixels} into one pinned
 // blob, ships it with a single H2D copy and launches the two passes.  d_out: [n][S][S][3] f32 in HBM.
 // ---------------------------------------------------------------------------------------------
-bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out) {
+void free_preprocess_slots(clip_ctx * ctx) {
+    for (auto & sl : ctx->pre_slot) {
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        sl = clip_ctx::PreSlot();
+    }
+    if (ctx->pre_copy_stream) (void)hipStreamDestroy(ctx->pre_copy_stream);
+    ctx->pre_copy_stream = nullptr;
+}
+
+// slot < 0: one staging blob, the stream is synchronised first (the blob of the previous call may still be in use), H2D on ctx->stream.
+// slot 0 / 1 (calls of several chunks, api.cpp encode_u8_to_device): double-buffered staging — the host fills pinned slot s while the
+// GPU still works on the other slot's chunk, the copy travels on a copy stream under that chunk's forward pass, and the only waits are
+// events (this slot's previous H2D before the host overwrites the pinned blob; its previous kernels before the copy overwrites the
+// device blob).  d_out may be the same buffer for every chunk: the kernels writing it are stream-ordered behind the forward reading it.
+bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out, int slot) {
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
         return false;
@@ -211,15 +228,46 @@ bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, 
     const size_t o_wp = up(o_ip + ipool.size() * sizeof(int)), o_raw = up(o_wp + wpool.size() * sizeof(double));
     const size_t host_bytes = up(o_raw + raw_bytes), total = host_bytes + hbuf_floats * sizeof(float);
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);   // the pinned blob / device buffer of the previous call may still be in use
-    if (!ensure_pinned(ctx, host_bytes)) { fprintf(stderr, "clip (hip): cannot pin %zu MB\n", host_bytes >> 20); return false; }
-    if (ctx->pre_bytes < total) {
-        if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
-        ctx->pre_buf = nullptr; ctx->pre_bytes = 0;
-        if (hipMalloc(&ctx->pre_buf, total) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "clip (hip): cannot allocate %zu MB for preprocessing\n", total >> 20); return false; }
-        ctx->pre_bytes = total;
+    uint8_t * h = nullptr, * dv = nullptr;
+    clip_ctx::PreSlot * sl = slot >= 0 ? &ctx->pre_slot[slot & 1] : nullptr;
+    if (!sl) {
+        (void)hipStreamSynchronize(ctx->stream);   // the pinned blob / device buffer of the previous call may still be in use
+        if (!ensure_pinned(ctx, host_bytes)) { fprintf(stderr, "clip (hip): cannot pin %zu MB\n", host_bytes >> 20); return false; }
+        if (ctx->pre_bytes < total) {
+            if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
+            ctx->pre_buf = nullptr; ctx->pre_bytes = 0;
+            if (hipMalloc(&ctx->pre_buf, total) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "clip (hip): cannot allocate %zu MB for preprocessing\n", total >> 20); return false; }
+            ctx->pre_bytes = total;
+        }
+        h = (uint8_t *)ctx->pinned;
+        dv = (uint8_t *)ctx->pre_buf;
+    } else {
+        if (!ctx->pre_copy_stream && hipStreamCreateWithFlags(&ctx->pre_copy_stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (!sl->ev_h2d && (hipEventCreateWithFlags(&sl->ev_h2d, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming) != hipSuccess)) return false;
+        if (sl->pin_bytes < host_bytes || sl->dev_bytes < total) {       // (re)allocation: nothing may still use the old buffers
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->pre_copy_stream);
+            if (sl->pin_bytes < host_bytes) {
+                if (sl->pin) (void)hipHostFree(sl->pin);
+                sl->pin = nullptr; sl->pin_bytes = 0;
+                const size_t want = host_bytes + host_bytes / 8;
+                if (hipHostMalloc(&sl->pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "clip (hip): cannot pin %zu MB\n", want >> 20); return false; }
+                sl->pin_bytes = want;
+            }
+            if (sl->dev_bytes < total) {
+                if (sl->dev) (void)hipFree(sl->dev);
+                sl->dev = nullptr; sl->dev_bytes = 0;
+                const size_t want = total + total / 8;
+                if (hipMalloc(&sl->dev, want) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "clip (hip): cannot allocate %zu MB for preprocessing\n", want >> 20); return false; }
+                sl->dev_bytes = want;
+            }
+            sl->used = false;
+        }
+        if (sl->used && hipEventSynchronize(sl->ev_h2d) != hipSuccess) return false;     // the previous copy out of this pinned blob has finished
+        h = (uint8_t *)sl->pin;
+        dv = (uint8_t *)sl->dev;
     }
-    uint8_t * h = (uint8_t *)ctx->pinned;
     memcpy(h + o_desc, desc.data(), desc.size() * sizeof(PreImg));
     memcpy(h + o_dir, dir.data(), dir.size() * sizeof(PreTaps));
     memcpy(h + o_ip, ipool.data(), ipool.size() * sizeof(int));
@@ -233,10 +281,20 @@ bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, 
             });
         for (auto & th : pool) th.join();
     }
-    uint8_t * dv = (uint8_t *)ctx->pre_buf;
-    if (hipMemcpyAsync(dv, h, host_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+    if (!sl) {
+        if (hipMemcpyAsync(dv, h, host_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+    } else {
+        hipStream_t cs = ctx->pre_copy_stream;
+        if (sl->used && hipStreamWaitEvent(cs, sl->ev_done, 0) != hipSuccess) return false;      // the kernels that read this device blob two chunks ago
+        if (hipMemcpyAsync(dv, h, host_bytes, hipMemcpyHostToDevice, cs) != hipSuccess) return false;
+        if (hipEventRecord(sl->ev_h2d, cs) != hipSuccess || hipStreamWaitEvent(ctx->stream, sl->ev_h2d, 0) != hipSuccess) return false;
+    }
     launch_preprocess(dv + o_raw, (const PreImg *)(dv + o_desc), (const PreTaps *)(dv + o_dir), (const double *)(dv + o_wp), (const int *)(dv + o_ip),
                       (float *)(dv + host_bytes), d_out, n, S, max_rows, ctx->image_mean, ctx->image_std, ctx->stream);
+    if (sl) {
+        if (hipEventRecord(sl->ev_done, ctx->stream) != hipSuccess) return false;
+        sl->used = true;
+    }
     return hipGetLastError() == hipSuccess;
 }
 

@@ -535,8 +535,9 @@ def _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=0.3, outlier=20.0):
     raw2 = ref.quantize(tid, W2)
     Wd2 = ref.dequantize(tid, raw2, N2, h).astype(np.float64)
     A = rng.standard_normal((M, K1)).astype(np.float32)
-    resid = (rng.standard_normal((M, h)) * 2.5 + mean_shift).astype(np.float32)
-    resid[:, rng.integers(0, h, size=2)] *= outlier         # outlier channels of the residual stream
+    resid = rng.standard_normal((M, h)) * 2.5
+    resid[:, rng.integers(0, h, size=2)] *= outlier         # outlier channels of the residual stream (about zero), then the common mode
+    resid = (resid + mean_shift).astype(np.float32)
     b1 = (rng.standard_normal(h) * 0.1).astype(np.float32)
     g = (1 + rng.standard_normal(h) * 0.2).astype(np.float32)
     beta = (rng.standard_normal(h) * 0.1).astype(np.float32)

@@ -463,6 +463,26 @@ def test_gpu_preprocessing_is_bit_identical_to_host(gpu, fixture_cache, config, 
     assert np.array_equal(clip.encode_images_u8(more), clip.encode_images(np.stack([clip.preprocess(im) for im in more])))
 
 
+def test_u8_encode_of_several_chunks_is_the_chunkwise_result(gpu, fixture_cache):
+    """clip_amd_image_batch_encode_u8 beyond 256 images per call: double-buffered staging (the host fills the next chunk's pinned blob and
+    a copy stream ships it while the GPU preprocesses and encodes the current chunk; round 4).  The embeddings must be the bits of the
+    same images encoded chunk by chunk through the single-slot path, for mixed image sizes, twice through the same context (slot re-use),
+    and both the contiguous-ndarray and the list form of the wrapper."""
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=False, vision=True)
+    clip = gpu.Clip(p, device=0)
+    rng = np.random.default_rng(12)
+    sizes = [(32, 32), (40, 64), (33, 90), (64, 48), (100, 37)]
+    images = [rng.integers(0, 256, size=sizes[i % len(sizes)] + (3,), dtype=np.uint8) for i in range(700)]      # 3 chunks: 256 + 256 + 188
+    want = np.concatenate([clip.encode_images_u8(images[i:i + 256]) for i in range(0, 700, 256)])
+    for _ in range(2):
+        assert np.array_equal(clip.encode_images_u8(images), want)
+    block = rng.integers(0, 256, size=(520, 32, 32, 3), dtype=np.uint8)                                         # one contiguous [B, ny, nx, 3] block
+    want_b = np.concatenate([clip.encode_images_u8(list(block[i:i + 256])) for i in range(0, 520, 256)])
+    assert np.array_equal(clip.encode_images_u8(block), want_b)
+    assert np.array_equal(clip.encode_images_u8(images[:300]), want[:300])       # a shorter multi-chunk call afterwards
+    clip.close()
+
+
 def test_batched_zero_shot_on_gpu_matches_per_image_reference_composition(gpu, fixture_cache):
     """clip_amd_zero_shot_label_images (labels encoded once, images preprocessed + encoded + scored on the
     GPU) == clip_zero_shot_label_image called per image (host scoring with the reference arithmetic)."""
