@@ -165,6 +165,21 @@ def algorithmic_work(vc, tc, ftype, n_img, text_lens):
     return fl, by
 
 
+def pruned_flops(vc, tc, n_img, text_lens):
+    """FLOPs the library does NOT execute although SURVEY 8(d) counts them: behind the last layer's attention only the pooled row of every
+    sequence is needed (class token / last token), so the last out-projection and FFN run on one row per sequence (csrc/forward.cpp
+    pooled_tail) whenever a tower has more than 64 token rows.  The roofline fractions keep the SURVEY figure (algorithmic work per unit)."""
+    cut = 0.0
+    if n_img:
+        h, ff, T = vc["hidden_size"], vc["n_intermediate"], (vc["image_size"] // vc["patch_size"]) ** 2 + 1
+        if n_img * T > 64:
+            cut += n_img * (T - 1) * 2.0 * (h * h + 2 * h * ff)
+    if len(text_lens) and sum(text_lens) > 64:
+        h, ff = tc["hidden_size"], tc["n_intermediate"]
+        cut += sum(n - 1 for n in text_lens) * 2.0 * (h * h + 2 * h * ff)
+    return cut
+
+
 def matrix_cell(torch, clip_cpp_amd, synth, cache, name, local_rank, steps=None, preheat=0.3, warmup=3):
     """One cell of the north_star target matrix, measured like the headline (inputs resident in HBM, the two towers of a step on two
     HIP streams, K timed steps between synchronisations) but rank-local and outside the headline's timed region."""
@@ -560,6 +575,10 @@ def main():
              "t_mfma_us": round(t_mfma_ws * 1e6, 2), "t_hbm_us": round(t_hbm_ws * 1e6, 2),
              "achieved_tflops": round(fl_step / (ms_step * 1e-3) / 1e12, 2), "achieved_gbs": round(by_step / (ms_step * 1e-3) / 1e9, 1),
              "frac": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4)}
+    if os.environ.get("CLIP_AMD_PRUNE_LAST", "1") != "0":
+        whole["executed_flops_per_step"] = fl_step - pruned_flops(vc, tc, batch, [len(t) for t in texts])
+        whole["executed_note"] = ("the last layer's out-projection + FFN run on the pooled row of every sequence only (same embeddings); `frac` and "
+                                  "`achieved_tflops` use the SURVEY 8(d) algorithmic FLOPs, executed_flops_per_step is what the kernels multiply")
 
     roofline = None
     kernels = None

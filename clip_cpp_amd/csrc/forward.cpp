@@ -274,12 +274,13 @@ bool run_layers_skinny_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h
 
 // L x { LN1, QKV, attention, out-proj(+res), LN2, FFN-up(+act), FFN-down(+res) }   (clip.cpp:1342-1423 / :1064-1143)
 bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
-                const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid) {
+                const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid, bool prune_last) {
     hipStream_t s = ctx->stream;
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
-    for (const DevLayer & l : tw.layers) {
+    for (size_t li = 0; li < tw.layers.size(); li++) {
+        const DevLayer & l = tw.layers[li];
         const LayerPanels lp = dequant_layer(ctx, l, rows);
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
@@ -297,6 +298,7 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
                 return false;
             }
         }
+        if (prune_last && li + 1 == tw.layers.size()) break;     // the rest of the last layer runs on the pooled rows only (pooled_tail)
         GemmParams po;
         po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x; po.w16_pre = lp.o;
         gemm(ctx, "gemm_out", po, EPI_RESID_F32);
@@ -320,7 +322,7 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
 // Precondition: xn = fp16(x * ln1_w of layer 0) and stats = ONE slot per row over all h columns (launch_layernorm_prep / launch_text_embed).
 bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
                      const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid,
-                     float2 * stats, int stats_stride, float * mu) {
+                     float2 * stats, int stats_stride, float * mu, bool prune_last) {
     hipStream_t s = ctx->stream;
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
@@ -355,6 +357,7 @@ bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int n
                 return false;
             }
         }
+        if (prune_last && li + 1 == tw.layers.size()) break;     // the rest of the last layer runs on the pooled rows only (pooled_tail)
         GemmParams po;
         po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x; po.w16_pre = lp.o;
         produce(po, l.ln2_w);
@@ -368,6 +371,36 @@ bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int n
         produce(p2, li + 1 < tw.layers.size() ? tw.layers[li + 1].ln1_w : nullptr);
         gemm(ctx, "gemm_ffn_down", p2, EPI_RESID_F32);
     }
+    return true;
+}
+
+// Only ONE row per sequence leaves the tower — the class-token row of an image (reference clip.cpp:1426-1431), the last token of a text
+// (:1154-1155) — and a row of the last layer's out-projection / FFN depends on no other row.  So the last layer runs q/k/v and attention on
+// every row (keys and values of all tokens feed the pooled query) and everything behind the attention on the `n` pooled rows only:
+// 1 / T of the out-projection and of both FFN GEMMs, i.e. ~(9 / 12) / L of the tower's linear FLOPs for free (ViT-B/32 batch 256: three
+// GEMMs of 12800 rows become three of 256).  Same arithmetic per row as the full-row layer (LayerNorm launch form), different tiles.
+// xp [n][h] f32 (out: the pooled rows of the final residual stream), ap / xnp [n][h] fp16, midp [n][ff] fp16: workspace of the caller.
+bool pooled_tail(clip_ctx * ctx, const DevLayer & l, int n, int h, int ff, float eps, const float * x, const half_t * att, const int * in_rows,
+                 int in_row_mul, float * xp, half_t * ap, half_t * xnp, half_t * midp) {
+    hipStream_t s = ctx->stream;
+    const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    {
+        ProfScope ps(ctx, "gather_pooled", n, h, 0, 0, (double)n * h * 12);
+        launch_gather_rows(x, att, in_rows, in_row_mul, n, h, xp, ap, s);
+    }
+    GemmParams po;
+    po.A = ap; po.lda = h; po.M = n; po.W = l.o; po.bias = l.o_b; po.out = xp; po.ldc = h; po.resid = xp;
+    gemm(ctx, "gemm_out_pooled", po, EPI_RESID_F32);
+    {
+        ProfScope ps(ctx, "layernorm", n, h, 0, 0, (double)n * h * 6);
+        launch_layernorm(xp, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, n, h, xnp, h, nullptr, 0, s);
+    }
+    GemmParams p1;
+    p1.A = xnp; p1.lda = h; p1.M = n; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = midp; p1.ldc = ff;
+    gemm(ctx, "gemm_ffn_up_pooled", p1, act);
+    GemmParams p2;
+    p2.A = midp; p2.lda = ff; p2.M = n; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = xp; p2.ldc = h; p2.resid = xp;
+    gemm(ctx, "gemm_ffn_down_pooled", p2, EPI_RESID_F32);
     return true;
 }
 
@@ -548,6 +581,10 @@ bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st) {
         st.col = c.take<half_t>((size_t)Bc * Np * V.patch.Kpad);
         st.pooled = c.take<half_t>((size_t)Bc * h);
         st.emb = c.take<float>((size_t)Bc * proj);
+        st.xp = c.take<float>((size_t)Bc * h);                // pooled rows of the last layer (pooled_tail)
+        st.ap = c.take<half_t>((size_t)Bc * h);
+        st.xnp = c.take<half_t>((size_t)Bc * h);
+        st.midp = c.take<half_t>((size_t)Bc * ff);
     };
     Carver sizer(nullptr);
     carve(sizer);
@@ -595,16 +632,23 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
             launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, st.xn, h, st.stats, s, ctx->ln_fold_centre ? st.mu : nullptr);
         else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
     }
+    // rows beyond the small-M path: the last layer's out-projection and FFN run on the Bc class-token rows only (pooled_tail)
+    const bool prune = ctx->prune_last && !skinny && !V.layers.empty() && T > 1;
     if (skinny && fold) {
         if (!run_layers_skinny_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr)) return false;
     } else if (skinny) {
         launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
         if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.qkv, st.att, st.mid)) return false;
     } else if (fold) {
-        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr)) return false;
-    } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid)) return false;
+        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr, prune)) return false;
+    } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, prune)) return false;
     // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
-    launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
+    if (prune) {
+        if (!pooled_tail(ctx, V.layers.back(), Bc, h, ff, hp.eps, x, st.att, nullptr, T, st.xp, st.ap, st.xnp, st.midp)) return false;
+        launch_layernorm(st.xp, h, nullptr, 1, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
+    } else {
+        launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
+    }
     GemmParams pj;
     pj.A = st.pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = st.emb; pj.ldc = proj;
     gemm(ctx, "gemm_proj", pj, EPI_F32);   // projection, no bias (:1443)
@@ -668,6 +712,8 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     const int st_stride = (rows + 63) & ~63;                   // LayerNorm-fold statistics: [<= h / 16 slots][st_stride rows] float2
     float2 * stats = nullptr;
     float * mu = nullptr;                                      // centring offsets of the folded LayerNorms: [2][st_stride]
+    float * xp = nullptr;                                      // pooled rows of the last layer (pooled_tail)
+    half_t * ap = nullptr, * xnp = nullptr, * midp = nullptr;
     auto carve = [&](Carver & c, float *& x, half_t *& xn, half_t *& qkv, half_t *& att, half_t *& mid, half_t *& pooled,
                      float *& emb, int *& seq, int *& last) {
         stats = c.take<float2>((size_t)(h / 16) * st_stride);
@@ -681,6 +727,10 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         emb = c.take<float>((size_t)n_texts * proj);
         seq = c.take<int>((size_t)n_texts + 1);
         last = c.take<int>((size_t)n_texts);
+        xp = c.take<float>((size_t)n_texts * h);
+        ap = c.take<half_t>((size_t)n_texts * h);
+        xnp = c.take<half_t>((size_t)n_texts * h);
+        midp = c.take<half_t>((size_t)n_texts * ff);
     };
     float *x, *emb;
     half_t *xn, *qkv, *att, *mid, *pooled;
@@ -762,6 +812,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     auto launch_all = [&]() -> bool {
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
         const bool fold = ctx->ln_fold && !Tw.layers.empty() && (ctx->ln_fold_force || fold_pays(Tw, rows));
+        const bool prune = ctx->prune_last && !skinny && !Tw.layers.empty() && rows > n_texts;
         if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
             launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats, ctx->ln_fold_centre ? mu : nullptr);
         else launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s);  // (:1059-1061)
@@ -771,10 +822,15 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, qkv, att, mid)) return false;
         } else if (fold) {
-            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride, ctx->ln_fold_centre ? mu : nullptr)) return false;
-        } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid)) return false;
+            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride, ctx->ln_fold_centre ? mu : nullptr, prune)) return false;
+        } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, prune)) return false;
         // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
-        launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+        if (prune) {    // ... and so is everything behind the last layer's attention: out-projection + FFN on the n_texts last-token rows only
+            if (!pooled_tail(ctx, Tw.layers.back(), n_texts, h, ff, hp.eps, x, att, last, 1, xp, ap, xnp, midp)) return false;
+            launch_layernorm(xp, h, nullptr, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+        } else {
+            launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+        }
         GemmParams pj;
         pj.A = pooled; pj.lda = h; pj.M = n_texts; pj.W = Tw.proj; pj.out = emb; pj.ldc = proj;
         gemm(ctx, "gemm_proj", pj, EPI_F32);     // (:1160)

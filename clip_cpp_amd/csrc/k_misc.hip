@@ -575,6 +575,24 @@ void launch_layernorm_prep(const float * x, int ldx, const float * w, const floa
 #undef CLIPAMD_LNP
 }
 
+// Pooled rows out of the last layer (forward.cpp pooled_tail): xp[r] = x[src(r)] (f32) and ap[r] = a[src(r)] (fp16), src(r) = in_rows[r] or
+// r * in_row_mul — the CLS rows b * T of the vision tower (reference clip.cpp:1426-1431), the last-token rows of the text tower (:1154-1155).
+namespace {
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float * __restrict__ x, const half_t * __restrict__ a, const int * __restrict__ in_rows,
+                                                          int in_row_mul, int rows, int h, float * __restrict__ xp, half_t * __restrict__ ap) {
+    const int r = blockIdx.x;
+    const long src = in_rows ? (long)in_rows[r] : (long)r * in_row_mul;
+    for (int c = threadIdx.x * 4; c < h; c += 256 * 4) {
+        *(f4 *)(xp + (size_t)r * h + c) = *(const f4 *)(x + (size_t)src * h + c);
+        *(uint2 *)(ap + (size_t)r * h + c) = *(const uint2 *)(a + (size_t)src * h + c);
+    }
+}
+}  // namespace
+void launch_gather_rows(const float * x, const half_t * a, const int * in_rows, int in_row_mul, int rows, int h, float * xp, half_t * ap, hipStream_t stream) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, stream, x, a, in_rows, in_row_mul, rows, h, xp, ap);
+}
+
 // The ragged-batch metadata of a text call (sequence starts, last-token rows) from a pinned, device-mapped host slot into the workspace,
 // by ONE workgroup; when the slot has been read it stamps `done` (mapped host memory) so that the host can re-use the slot without a HIP
 // event: hipEventRecord per call made the runtime stall once for ~35 ms after a few hundred to ~1000 calls (profiles/r03_step_spikes.txt).

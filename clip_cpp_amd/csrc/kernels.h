@@ -217,6 +217,9 @@ bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform,
 // imgs [B][S][S][3] interleaved, f32 or (imgs_f16) already rounded to fp16 -> col [B*Np][Kpad] fp16, k = (c*P + ky)*P + kx, zero padded.
 void launch_im2col(const void * imgs, bool imgs_f16, half_t * col, int B, int S, int P, int Kpad, hipStream_t stream);
 
+// pooled rows of the last layer: xp[r] = x[src(r)], ap[r] = a[src(r)], src(r) = in_rows[r] or r * in_row_mul (h % 4 == 0)
+void launch_gather_rows(const float * x, const half_t * a, const int * in_rows, int in_row_mul, int rows, int h, float * xp, half_t * ap, hipStream_t stream);
+
 // x[b*T + 0][:] = class_embd + pos[0]   (reference clip.cpp:1315-1331, class-token row)
 void launch_cls_rows(float * x, const float * class_embd, const float * pos, int B, int T, int h, hipStream_t stream);
 

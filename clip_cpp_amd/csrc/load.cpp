@@ -583,6 +583,8 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         const char * e = getenv("CLIP_AMD_LNFOLD");
         ctx->ln_fold = !(e && e[0] == '0');
         ctx->ln_fold_force = e && e[0] == '2';       // tuning: fold even where forward.cpp fold_pays() says the LayerNorm launches are cheaper
+        const char * ep = getenv("CLIP_AMD_PRUNE_LAST");
+        ctx->prune_last = !(ep && ep[0] == '0');
         const char * ec = getenv("CLIP_AMD_LNFOLD_CENTRE");
         ctx->ln_fold_centre = !(ec && ec[0] == '0');  // A/B: the r03 form, fp16(x gamma) without the per-row offset
     }

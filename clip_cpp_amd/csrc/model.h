@@ -140,6 +140,7 @@ struct clip_ctx {
     // residual epilogues and read by the LayerNorm-fused projections of the next sub-layer
     float2 * sk_stats = nullptr;
     bool ln_fold_force = false;      // CLIP_AMD_LNFOLD=2
+    bool prune_last = true;          // the last layer's out-projection + FFN run on the pooled rows only (forward.cpp pooled_tail; CLIP_AMD_PRUNE_LAST=0: every row, for A/B)
     bool ln_fold_centre = true;      // the folded operand is built about the row's mean at the previous LayerNorm (kernels.h GemmParams::xg_mu; CLIP_AMD_LNFOLD_CENTRE=0: the r03 form, for A/B)
     bool ln_fold = true;             // LayerNorm folded into the GEMM epilogues for > 64 rows (CLIP_AMD_LNFOLD=0: the two-launch form, for A/B)
     // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
@@ -184,6 +185,8 @@ struct VisionStage {
     half_t * xn = nullptr, * qkv = nullptr, * att = nullptr, * mid = nullptr, * col = nullptr, * pooled = nullptr;
     float2 * stats = nullptr;
     float * mu = nullptr;
+    float * xp = nullptr;            // pooled rows of the last layer (forward.cpp pooled_tail)
+    half_t * ap = nullptr, * xnp = nullptr, * midp = nullptr;
 };
 bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st);
 bool vision_stage_patch(clip_ctx * ctx, const VisionStage & st, const void * imgs, int i0, int n);

@@ -279,6 +279,38 @@ def test_layernorm_fold_matches_the_layernorm_kernel_form_end_to_end(gpu, fixtur
     np.testing.assert_allclose(got_t, ref_t, atol=atol)
 
 
+@pytest.mark.parametrize("config,ftype,n_img", [("b32", "q4_0", 40), ("b32", "f16", 5), ("tiny14", "q5_1", 9), ("tiny", "q8_0", 70)])
+def test_last_layer_on_pooled_rows_only_matches_the_full_row_form(gpu, fixture_cache, monkeypatch, config, ftype, n_img):
+    """Round 4: behind the last layer's attention only the pooled row of each sequence is computed (class token, reference clip.cpp:1426-1431;
+    last token of a text, :1154-1155) — out-projection + LayerNorm + FFN on B rows instead of B x T.  Same arithmetic per row, other tiles:
+    against CLIP_AMD_PRUNE_LAST=0 (every row through the last layer) both towers agree to fp32 re-association / one fp16 rounding
+    (1 - cos <= 1e-6), and the profile shows the pooled GEMMs at M = batch."""
+    p = fixtures.cached_model(fixture_cache, config, ftype)
+    S = fixtures.CONFIGS[config]["v"]["S"]
+    imgs = fixtures.synthetic_images(n_img, S, seed=78)
+    texts = _ragged_text_batch(24, fixtures.CONFIGS[config]["t"]["npos"], seed=4)
+    monkeypatch.delenv("CLIP_AMD_PRUNE_LAST", raising=False)
+    clip = gpu.Clip(p, device=0)
+    got_i, got_t = clip.encode_images(imgs), clip.encode_texts(texts)
+    clip.profile(True)
+    clip.encode_images(imgs)
+    clip.encode_texts(texts)
+    rep = clip.profile_report(reset=True)
+    clip.close()
+    pooled = [k for k in rep if "_pooled" in k and k.startswith("gemm")]
+    assert any((":%dx" % n_img) in k for k in pooled) and any((":%dx" % len(texts)) in k for k in pooled), sorted(rep)
+    monkeypatch.setenv("CLIP_AMD_PRUNE_LAST", "0")
+    clip0 = gpu.Clip(p, device=0)
+    ref_i, ref_t = clip0.encode_images(imgs), clip0.encode_texts(texts)
+    clip0.close()
+    monkeypatch.delenv("CLIP_AMD_PRUNE_LAST", raising=False)
+    assert np.all(one_minus_cos(got_i, ref_i) <= 1e-6), one_minus_cos(got_i, ref_i).max()
+    assert np.all(one_minus_cos(got_t, ref_t) <= 1e-6), one_minus_cos(got_t, ref_t).max()
+    atol = 3e-4 if config == "b32" else 1e-3
+    np.testing.assert_allclose(got_i, ref_i, atol=atol)
+    np.testing.assert_allclose(got_t, ref_t, atol=atol)
+
+
 @pytest.mark.parametrize("ftype,dc", [("f16", 6.0), ("q4_0", 6.0), ("f16", 20.0)])
 def test_layernorm_fold_under_a_large_common_mode_end_to_end(gpu, fixture_cache, monkeypatch, ftype, dc):
     """a ViT-B/32-shaped model whose residual rows carry a common mode of |mean| / std >= ~5 that drifts from layer
