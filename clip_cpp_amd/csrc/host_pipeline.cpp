@@ -377,7 +377,8 @@ struct MultiCtx {
     bool collective = false;              // the all-gather runs (G > 1, or G == 1 with CLIP_AMD_MULTI_FORCE_RCCL=1)
     PackPool replicas;                    // one persistent host thread per replica beyond the first (the caller drives replica 0)
     // two-tower calls (multi_run_pair): a second context per device carries the text tower on its own stream (a context owns ONE
-    // activation workspace and ONE split-K workspace, so the towers of a step cannot share one), loaded on the first such call
+    // activation workspace and ONE split-K workspace, so the towers of a step cannot share one): replica g's weight-sharing sibling
+    // (load.cpp sibling_context: no second copy of the weights), created on the first such call
     std::vector<clip_ctx *> twin;
     std::vector<hipEvent_t> ev_fork, ev_join;
 };
@@ -453,7 +454,7 @@ void multi_free(clip_ctx * primary) {
         (void)hipSetDevice(mc->twin[g]->device);
         if (g < (int)mc->ev_fork.size() && mc->ev_fork[g]) (void)hipEventDestroy(mc->ev_fork[g]);
         if (g < (int)mc->ev_join.size() && mc->ev_join[g]) (void)hipEventDestroy(mc->ev_join[g]);
-        free_model(mc->twin[g]);
+        // (the twin is replica g's sibling context: free_model of the replica frees it)
     }
     for (int g = 1; g < mc->G; g++) free_model(mc->rep[g]);
     delete mc;
@@ -564,12 +565,13 @@ bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * 
         clip_ctx * c = mc->rep[g];
         (void)hipSetDevice(c->device);
         if (!mc->twin[g]) {
-            mc->twin[g] = load_model(primary->path.c_str(), 0, c->device);
+            mc->twin[g] = sibling_context(c);        // same device, the replica's weight image, own stream + workspace (freed with the replica)
             if (!mc->twin[g] || hipEventCreateWithFlags(&mc->ev_fork[g], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&mc->ev_join[g], hipEventDisableTiming) != hipSuccess) { okv[g] = 0; return; }
             (void)hipSetDevice(c->device);
         }
         clip_ctx * t = mc->twin[g];
+        c->sibling_busy = true;                      // the sibling carries the text tower: the vision half of this call is not split over it
         void * sp = mc->send[g], * rp = mc->recv[g];
         size_t sb = mc->send_floats[g] * 4, rb = mc->recv_floats[g] * 4;
         const bool grew = sb < (size_t)per_dev * proj * 4 || rb < (size_t)G * per_dev * proj * 4;
@@ -588,6 +590,7 @@ bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * 
         if (ht > lt && !run_txt(g, t, lt, ht, s_txt)) okv[g] = 0;
         // join: the all-gather on the replica stream sees both towers
         if (hipEventRecord(mc->ev_join[g], t->stream) != hipSuccess || hipStreamWaitEvent(c->stream, mc->ev_join[g], 0) != hipSuccess) okv[g] = 0;
+        c->sibling_busy = false;
     };
     mc->replicas.run(G, work);
     for (int g = 0; g < G; g++)

@@ -371,6 +371,8 @@ std::string kernel_limits(const char * tower, int hidden, int n_head, int proj, 
 
 }  // namespace
 
+namespace { bool alloc_runtime_buffers(clip_ctx * ctx); }
+
 clip_ctx * load_model(const char * fname, int verbosity, int device) {
     GgufFile g;
     std::string err;
@@ -547,15 +549,11 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
     ctx->device = device;
     { const char * g = getenv("CLIP_AMD_GRAPHS"); if (g && g[0] == '0') ctx->graphs_enabled = false; }
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    ctx->stream = ctx->own_stream;
-    {   // split-K workspace (small-M GEMMs): 64 MB of partial tiles + 4096 ticket counters
-        const size_t nfl = (size_t)16 << 20;
-        void * w = nullptr, * c = nullptr;
-        if (hipMalloc(&w, nfl * sizeof(float)) != hipSuccess || hipMalloc(&c, 4096 * sizeof(unsigned)) != hipSuccess || hipMemset(c, 0, 4096 * sizeof(unsigned)) != hipSuccess)
-            return fail("hipMalloc (split-K workspace) failed");
-        ctx->sk_ws = (float *)w; ctx->sk_ws_floats = nfl; ctx->sk_cnt = (unsigned *)c; ctx->sk_cnt_n = 4096;
-        if (hipMalloc((void **)&ctx->sk_stats, (size_t)2 * SKINNY_MAX_ROWS * 128 * sizeof(float2)) != hipSuccess) return fail("hipMalloc (LayerNorm statistics) failed");
+    if (!alloc_runtime_buffers(ctx)) return fail("stream / split-K workspace / LayerNorm statistics allocation failed");
+    {
+        int lo = 0, hi = 0;      // CLIP_AMD_SPLIT=min,max: batch sizes whose forward is split over two streams (forward.cpp); "0,0" = never
+        const char * e = getenv("CLIP_AMD_SPLIT");
+        if (e && sscanf(e, "%d,%d", &lo, &hi) == 2) { ctx->split_min = lo; ctx->split_max = hi; }
     }
     ctx->weights_bytes = L.st.size + 256;
     if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");
@@ -592,9 +590,51 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     return ctx;
 }
 
+namespace {
+bool alloc_runtime_buffers(clip_ctx * ctx) {   // stream + split-K workspace (64 MB of partial tiles, 4096 ticket counters) + small-M LayerNorm statistics
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return false;
+    ctx->stream = ctx->own_stream;
+    const size_t nfl = (size_t)16 << 20;
+    void * w = nullptr, * c = nullptr;
+    if (hipMalloc(&w, nfl * sizeof(float)) != hipSuccess || hipMalloc(&c, 4096 * sizeof(unsigned)) != hipSuccess || hipMemset(c, 0, 4096 * sizeof(unsigned)) != hipSuccess) return false;
+    ctx->sk_ws = (float *)w; ctx->sk_ws_floats = nfl; ctx->sk_cnt = (unsigned *)c; ctx->sk_cnt_n = 4096;
+    return hipMalloc((void **)&ctx->sk_stats, (size_t)2 * SKINNY_MAX_ROWS * 128 * sizeof(float2)) == hipSuccess;
+}
+}  // namespace
+
+// A second context on the owner's device that multiplies the owner's weight image (no reload, no second copy in HBM): own stream,
+// own activation workspace / split-K buffers / statistics.  Encoder state only — no tokenizer tables, no host pipeline.
+clip_ctx * sibling_context(clip_ctx * owner) {
+    if (!owner || owner->device < 0 || owner->weights_borrowed) return nullptr;
+    if (owner->sibling) return owner->sibling;
+    (void)hipSetDevice(owner->device);
+    clip_ctx * c = new clip_ctx();
+    c->has_text_encoder = owner->has_text_encoder; c->has_vision_encoder = owner->has_vision_encoder; c->use_gelu = owner->use_gelu; c->ftype = owner->ftype;
+    c->text_hparams = owner->text_hparams; c->vision_hparams = owner->vision_hparams;
+    memcpy(c->image_mean, owner->image_mean, sizeof c->image_mean); memcpy(c->image_std, owner->image_std, sizeof c->image_std);
+    c->device = owner->device;
+    c->vision = owner->vision; c->text = owner->text;            // device pointers into the owner's weight image
+    c->weights_borrowed = true;
+    c->owner = owner;
+    c->ln_fold = owner->ln_fold; c->ln_fold_force = owner->ln_fold_force; c->ln_fold_centre = owner->ln_fold_centre; c->prune_last = owner->prune_last;
+    c->graphs_enabled = false;                                   // (its launches are captured into the OWNER's graphs)
+    c->split_min = c->split_max = 0;
+    c->verbosity = 0; c->path = owner->path;
+    if (!alloc_runtime_buffers(c) || hipEventCreateWithFlags(&owner->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&owner->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        fprintf(stderr, "clip (hip): cannot create the sibling context\n");
+        free_model(c);
+        return nullptr;
+    }
+    owner->sibling = c;
+    return c;
+}
+
 void free_model(clip_ctx * ctx) {
     if (!ctx) return;
     if (ctx->multi) multi_free(ctx);     // replicas on the other devices, RCCL communicators
+    if (ctx->sibling) { free_model(ctx->sibling); ctx->sibling = nullptr; }
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
@@ -606,10 +646,12 @@ void free_model(clip_ctx * ctx) {
         }
         if (ctx->meta.done) (void)hipHostFree((void *)ctx->meta.done);
         if (ctx->ev_stream_switch) (void)hipEventDestroy(ctx->ev_stream_switch);
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
         for (auto & p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         drop_graphs(ctx);
         if (ctx->ws.base) (void)hipFree(ctx->ws.base);
-        if (ctx->weights_base) (void)hipFree(ctx->weights_base);
+        if (ctx->weights_base && !ctx->weights_borrowed) (void)hipFree(ctx->weights_base);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         if (ctx->io_in) (void)hipFree(ctx->io_in);
         if (ctx->io_out) (void)hipFree(ctx->io_out);

@@ -123,6 +123,16 @@ struct clip_ctx {
     clipamd::HostPipe pipe;          // pinned double-buffered staging of clip_image_batch_encode (host_pipeline.cpp)
     clipamd::MetaRing meta;          // pinned ring for the text tower's per-call offsets
     void * multi = nullptr;          // clipamd::MultiCtx* when loaded with clip_amd_model_load_multi (replicas on the other devices)
+    // Sibling context on the same device SHARING this context's weight image (load.cpp sibling_context): own stream, activation
+    // workspace and split-K buffers, no second copy of the weights.  Carries the second half of a mid-size batch (forward.cpp: one
+    // forward of 8-64 images leaves ~40 % of the chip idle — two half-batches on two streams fill it) and the text tower of the
+    // two-tower multi-GPU call.  Created on first use, freed with the owner.
+    clip_ctx * sibling = nullptr;
+    bool weights_borrowed = false;   // this IS a sibling: weights_base belongs to the owner
+    clip_ctx * owner = nullptr;      // (sibling only) the context whose captured graphs hold pointers into this one's workspace
+    bool sibling_busy = false;       // the sibling is carrying something else right now (the text tower of a two-tower multi call): no batch split
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_min = 8, split_max = 64;     // images per call for which the forward is split over the two contexts (CLIP_AMD_SPLIT=min,max; 0,0 = off)
     hipEvent_t ev_stream_switch = nullptr;   // orders a new stream behind the work queued on the previous one (clip_amd_set_stream)
     void * pre_buf = nullptr;        // device blob of the GPU preprocessing path (descriptors, taps, raw pixels, row buffer)
     size_t pre_bytes = 0;
@@ -171,6 +181,7 @@ namespace clipamd {
 
 // load.cpp
 clip_ctx * load_model(const char * fname, int verbosity, int device);
+clip_ctx * sibling_context(clip_ctx * owner);     // owner->sibling, created on first use (nullptr on failure)
 void free_model(clip_ctx * ctx);
 bool repack_for_test(int type, const void * w_raw, int64_t N, int64_t K, DevWeight & W, void ** dev_base);
 

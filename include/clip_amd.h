@@ -57,8 +57,8 @@ bool clip_amd_image_batch_encode_device_multi(struct clip_ctx * ctx, const float
 bool clip_amd_text_batch_encode_device_multi(struct clip_ctx * ctx, const int32_t * const * d_ids, const int32_t * h_offsets, int total, bool normalize,
                                              float * vec);
 /* Both towers of a step in ONE call: on every device the vision tower (reference clip.cpp:1247) runs on the replica's stream and the text
- * tower (clip.cpp:1016) on the stream of a twin context of that device (loaded on the first such call: a context owns one activation
- * workspace), forked and joined with events, then ONE grouped ncclAllGather of [rows_per_device(n_images) + rows_per_device(n_texts)]
+ * tower (clip.cpp:1016) on the stream of a sibling context of that device (created on the first such call: own activation workspace,
+ * the replica's weight image), forked and joined with events, then ONE grouped ncclAllGather of [rows_per_device(n_images) + rows_per_device(n_texts)]
  * rows per device; clip_amd_gathered_embeddings then holds n_devices such blocks (image rows first).  Shards as above; vec_img
  * [n_images][projection_dim] and vec_txt [n_texts][projection_dim] (host) may each be NULL.  Synchronous. */
 bool clip_amd_encode_pair_device_multi(struct clip_ctx * ctx, const float * const * d_imgs, int n_images, const int32_t * const * d_ids,
