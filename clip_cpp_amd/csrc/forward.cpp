@@ -522,29 +522,55 @@ void prof_collect(clip_ctx * ctx) {
 // ---------------------------------------------------------------------------------------------
 static bool vision_forward_one(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize);
 
-// One forward of 8-64 images leaves a good part of the chip idle (r03: three batch-32 requests in flight 50.6 k img/s against 30.7 k for
-// one): such a call runs as two half-batches on two streams — this context and its weight-sharing sibling (own workspace, own split-K
+// One forward of a few dozen images leaves a good part of the chip idle (r03: three batch-32 requests in flight 50.6 k img/s against
+// 30.7 k for one): such a call runs as two half-batches on two streams — this context and its weight-sharing sibling (own workspace, own split-K
 // buffers) — forked and joined with events, so that the two dependent launch chains fill each other's gaps.  Rows are independent of
 // each other, so each half is exactly the forward of those images at that batch size (deterministic; same kernels as a call of n / 2).
 static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
-    const bool split = !ctx->weights_borrowed && !ctx->sibling_busy && !ctx->profiling && ctx->has_vision_encoder && ctx->split_max > 0 && B >= ctx->split_min && B <= ctx->split_max && B >= 2;
-    clip_ctx * sib = nullptr;
+    bool split = !ctx->weights_borrowed && !ctx->sibling_busy && !ctx->profiling && ctx->has_vision_encoder && B >= 2;
+    if (split) {
+        if (ctx->split_max >= 0) split = B >= ctx->split_min && B <= ctx->split_max;           // CLIP_AMD_SPLIT
+        else {
+            // measured (profiles/r04_batch_split_sweep.txt, one forward vs two halves, hipGraph replay where it applies): ViT-B/32 q4_0
+            // +5.6 / +4.1 / +2.7 / +6.4 / +5.9 % at 16 / 24 / 32 / 48 / 64 images (800-3200 token rows), -3 ... -5 % at 4 / 8 / 96;
+            // ViT-L/14 f16 +23 / +11 / +5 % at 8 / 16 / 32 images (2056-8224 rows), -2 % at 4.  3 and 4 parts are slower everywhere.
+            const auto & hp = ctx->vision_hparams;
+            const int G = hp.image_size / hp.patch_size;
+            const long rows = (long)B * (G * G + 1);
+            split = hp.hidden_size >= 1024 ? (rows >= 2000 && rows <= 8400) : (rows >= 800 && rows <= 3300);
+        }
+    }
+    int ways = split ? std::min(ctx->split_ways, B) : 1;
+    clip_ctx * part_ctx[4] = {ctx, nullptr, nullptr, nullptr};
     if (split) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(ctx->stream, &cs);
-        sib = ctx->sibling ? ctx->sibling : (cs == hipStreamCaptureStatusNone ? sibling_context(ctx) : nullptr);   // (created outside captures only)
+        for (int w = 1; w < ways; w++) {
+            clip_ctx * have = w == 1 ? ctx->sibling : ctx->more_siblings[w - 2];
+            part_ctx[w] = have ? have : (cs == hipStreamCaptureStatusNone ? sibling_context(ctx, w - 1) : nullptr);   // (created outside captures only)
+            if (!part_ctx[w]) { ways = 1; break; }
+        }
     }
-    if (!sib) return vision_forward_one(ctx, d_imgs, B, d_out, normalize);
-    const int n1 = (B + 1) / 2, n2 = B - n1;
+    if (ways < 2) return vision_forward_one(ctx, d_imgs, B, d_out, normalize);
     const size_t per = (size_t)ctx->vision_hparams.image_size * ctx->vision_hparams.image_size * 3;
     const int proj = ctx->vision_hparams.projection_dim;
-    sib->input_f16 = ctx->input_f16;
-    const float * second = ctx->input_f16 ? (const float *)((const half_t *)d_imgs + (size_t)n1 * per) : d_imgs + (size_t)n1 * per;
-    if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(sib->stream, ctx->ev_fork, 0) != hipSuccess) return false;
-    const bool ok1 = vision_forward_one(ctx, d_imgs, n1, d_out, normalize);
-    const bool ok2 = vision_forward_one(sib, second, n2, d_out + (size_t)n1 * proj, normalize);
-    if (hipEventRecord(ctx->ev_join, sib->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess) return false;
-    return ok1 && ok2;
+    if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess) return false;
+    bool ok = true;
+    int b0 = 0;
+    for (int w = 0; w < ways; w++) {          // contiguous parts, sizes differing by at most one (larger first)
+        const int n = B / ways + (w < B % ways ? 1 : 0);
+        clip_ctx * c = part_ctx[w];
+        c->input_f16 = ctx->input_f16;
+        const float * src = ctx->input_f16 ? (const float *)((const half_t *)d_imgs + (size_t)b0 * per) : d_imgs + (size_t)b0 * per;
+        if (w > 0 && hipStreamWaitEvent(c->stream, ctx->ev_fork, 0) != hipSuccess) return false;
+        ok = vision_forward_one(c, src, n, d_out + (size_t)b0 * proj, normalize) && ok;
+        b0 += n;
+    }
+    for (int w = 1; w < ways; w++) {
+        hipEvent_t ej = w == 1 ? ctx->ev_join : ctx->ev_join_more[w - 2];
+        if (hipEventRecord(ej, part_ctx[w]->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ej, 0) != hipSuccess) return false;
+    }
+    return ok;
 }
 
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {

@@ -551,9 +551,9 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     { const char * g = getenv("CLIP_AMD_GRAPHS"); if (g && g[0] == '0') ctx->graphs_enabled = false; }
     if (!alloc_runtime_buffers(ctx)) return fail("stream / split-K workspace / LayerNorm statistics allocation failed");
     {
-        int lo = 0, hi = 0;      // CLIP_AMD_SPLIT=min,max: batch sizes whose forward is split over two streams (forward.cpp); "0,0" = never
+        int lo = 0, hi = 0, ways = 2;      // CLIP_AMD_SPLIT=min,max[,ways]: batch sizes whose forward is split over 2 (3, 4) streams (forward.cpp); "0,0" = never
         const char * e = getenv("CLIP_AMD_SPLIT");
-        if (e && sscanf(e, "%d,%d", &lo, &hi) == 2) { ctx->split_min = lo; ctx->split_max = hi; }
+        if (e && sscanf(e, "%d,%d,%d", &lo, &hi, &ways) >= 2) { ctx->split_min = lo; ctx->split_max = hi; ctx->split_ways = ways < 2 ? 2 : ways > 4 ? 4 : ways; }
     }
     ctx->weights_bytes = L.st.size + 256;
     if (hipMalloc(&ctx->weights_base, ctx->weights_bytes) != hipSuccess) return fail("hipMalloc of the weight image failed");
@@ -604,9 +604,10 @@ bool alloc_runtime_buffers(clip_ctx * ctx) {   // stream + split-K workspace (64
 
 // A second context on the owner's device that multiplies the owner's weight image (no reload, no second copy in HBM): own stream,
 // own activation workspace / split-K buffers / statistics.  Encoder state only — no tokenizer tables, no host pipeline.
-clip_ctx * sibling_context(clip_ctx * owner) {
-    if (!owner || owner->device < 0 || owner->weights_borrowed) return nullptr;
-    if (owner->sibling) return owner->sibling;
+clip_ctx * sibling_context(clip_ctx * owner, int index) {
+    if (!owner || owner->device < 0 || owner->weights_borrowed || index < 0 || index > 2) return nullptr;
+    clip_ctx *& slot = index == 0 ? owner->sibling : owner->more_siblings[index - 1];
+    if (slot) return slot;
     (void)hipSetDevice(owner->device);
     clip_ctx * c = new clip_ctx();
     c->has_text_encoder = owner->has_text_encoder; c->has_vision_encoder = owner->has_vision_encoder; c->use_gelu = owner->use_gelu; c->ftype = owner->ftype;
@@ -618,16 +619,17 @@ clip_ctx * sibling_context(clip_ctx * owner) {
     c->owner = owner;
     c->ln_fold = owner->ln_fold; c->ln_fold_force = owner->ln_fold_force; c->ln_fold_centre = owner->ln_fold_centre; c->prune_last = owner->prune_last;
     c->graphs_enabled = false;                                   // (its launches are captured into the OWNER's graphs)
-    c->split_min = c->split_max = 0;
+    c->split_min = c->split_max = 0;                             // (a sibling never splits)
     c->verbosity = 0; c->path = owner->path;
-    if (!alloc_runtime_buffers(c) || hipEventCreateWithFlags(&owner->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&owner->ev_join, hipEventDisableTiming) != hipSuccess) {
+    hipEvent_t & evj = index == 0 ? owner->ev_join : owner->ev_join_more[index - 1];
+    if (!alloc_runtime_buffers(c) || (!owner->ev_fork && hipEventCreateWithFlags(&owner->ev_fork, hipEventDisableTiming) != hipSuccess) ||
+        hipEventCreateWithFlags(&evj, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         fprintf(stderr, "clip (hip): cannot create the sibling context\n");
         free_model(c);
         return nullptr;
     }
-    owner->sibling = c;
+    slot = c;
     return c;
 }
 
@@ -635,6 +637,7 @@ void free_model(clip_ctx * ctx) {
     if (!ctx) return;
     if (ctx->multi) multi_free(ctx);     // replicas on the other devices, RCCL communicators
     if (ctx->sibling) { free_model(ctx->sibling); ctx->sibling = nullptr; }
+    for (clip_ctx *& ms : ctx->more_siblings) if (ms) { free_model(ms); ms = nullptr; }
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
@@ -648,6 +651,7 @@ void free_model(clip_ctx * ctx) {
         if (ctx->ev_stream_switch) (void)hipEventDestroy(ctx->ev_stream_switch);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+        for (hipEvent_t e : ctx->ev_join_more) if (e) (void)hipEventDestroy(e);
         for (auto & p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         drop_graphs(ctx);
         if (ctx->ws.base) (void)hipFree(ctx->ws.base);

@@ -128,11 +128,14 @@ struct clip_ctx {
     // forward of 8-64 images leaves ~40 % of the chip idle — two half-batches on two streams fill it) and the text tower of the
     // two-tower multi-GPU call.  Created on first use, freed with the owner.
     clip_ctx * sibling = nullptr;
+    clip_ctx * more_siblings[2] = {nullptr, nullptr};     // (3- / 4-way splits: CLIP_AMD_SPLIT=min,max,ways)
+    hipEvent_t ev_join_more[2] = {nullptr, nullptr};
+    int split_ways = 2;
     bool weights_borrowed = false;   // this IS a sibling: weights_base belongs to the owner
     clip_ctx * owner = nullptr;      // (sibling only) the context whose captured graphs hold pointers into this one's workspace
     bool sibling_busy = false;       // the sibling is carrying something else right now (the text tower of a two-tower multi call): no batch split
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int split_min = 8, split_max = 64;     // images per call for which the forward is split over the two contexts (CLIP_AMD_SPLIT=min,max; 0,0 = off)
+    int split_min = -1, split_max = -1;    // images per call for which the forward is split over two contexts; -1 = the measured default rule by token rows (forward.cpp); CLIP_AMD_SPLIT=min,max[,ways] overrides, 0,0 = off
     hipEvent_t ev_stream_switch = nullptr;   // orders a new stream behind the work queued on the previous one (clip_amd_set_stream)
     void * pre_buf = nullptr;        // device blob of the GPU preprocessing path (descriptors, taps, raw pixels, row buffer)
     size_t pre_bytes = 0;
@@ -181,7 +184,7 @@ namespace clipamd {
 
 // load.cpp
 clip_ctx * load_model(const char * fname, int verbosity, int device);
-clip_ctx * sibling_context(clip_ctx * owner);     // owner->sibling, created on first use (nullptr on failure)
+clip_ctx * sibling_context(clip_ctx * owner, int index = 0);     // owner->sibling (index 0) / more_siblings[index - 1], created on first use (nullptr on failure)
 void free_model(clip_ctx * ctx);
 bool repack_for_test(int type, const void * w_raw, int64_t N, int64_t K, DevWeight & W, void ** dev_base);
 

@@ -18,7 +18,7 @@ for spec in models:
     batches = (2, 4, 8, 16, 24, 32, 48, 64, 96, 128) if arch == "b32" else (2, 4, 8, 16, 32)
     for B in batches:
         row = []
-        for split in ("0,0", "2,128"):
+        for split in ("0,0", "2,128,2", "2,128,3", "2,128,4"):
             os.environ["CLIP_AMD_SPLIT"] = split
             clip = clip_cpp_amd.Clip(path, verbosity=0, device=0)
             S, proj = clip.vision_config["image_size"], clip.vision_config["projection_dim"]
@@ -37,6 +37,6 @@ for spec in models:
                     clip.encode_images_device(imgs.data_ptr(), B, out.data_ptr(), True)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / reps
-            row.append("%s: %7.3f ms %8.0f img/s" % ("one forward  " if split == "0,0" else "two halves   ", dt * 1e3, B / dt))
+            row.append("%s: %7.3f ms %8.0f img/s" % ("one forward" if split == "0,0" else "%s parts" % split[-1], dt * 1e3, B / dt))
             clip.close()
         print("%s %s B=%-4d | %s" % (arch, ftype, B, " | ".join(row)), flush=True)

@@ -298,7 +298,10 @@ def test_last_layer_on_pooled_rows_only_matches_the_full_row_form(gpu, fixture_c
     rep = clip.profile_report(reset=True)
     clip.close()
     pooled = [k for k in rep if "_pooled" in k and k.startswith("gemm")]
-    assert any((":%dx" % n_img) in k for k in pooled) and any((":%dx" % len(texts)) in k for k in pooled), sorted(rep)
+    T = (S // fixtures.CONFIGS[config]["v"]["P"]) ** 2 + 1
+    if n_img * T > 64:           # (up to 64 token rows the small-M kernels carry every layer: nothing to prune)
+        assert sum((":%dx" % n_img) in k for k in pooled) == 3, sorted(rep)
+    assert sum((":%dx" % len(texts)) in k for k in pooled) == 3, sorted(rep)
     monkeypatch.setenv("CLIP_AMD_PRUNE_LAST", "0")
     clip0 = gpu.Clip(p, device=0)
     ref_i, ref_t = clip0.encode_images(imgs), clip0.encode_texts(texts)
@@ -337,7 +340,7 @@ def test_mid_size_batch_split_over_two_streams_is_the_two_half_batches(gpu, fixt
     halves = np.concatenate([run(c0, imgs[:n1].contiguous())[0], run(c0, imgs[n1:].contiguous())[0]])
     whole = run(c0, imgs)[0]
     c0.close()
-    monkeypatch.setenv("CLIP_AMD_SPLIT", "2,64")
+    monkeypatch.setenv("CLIP_AMD_SPLIT", "2,64")     # (forced: the default rule splits by token rows, forward.cpp split_applies)
     c1 = gpu.Clip(p, device=0)
     same_ptr_out = torch.empty((B, proj), dtype=torch.float32, device="cuda")
     for i in range(5):                        # same pointers every time: eager, capture, replay x 3
