@@ -592,7 +592,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
                 launch_gemm4(p, epilogue, stream);
                 return;
             }
-            if (tile % 1000 == 259) tile = 256256;     // LayerNorm-folded launch: the four-wave kernel carries no fold code, the 8-wave 256 x 256 tile does
+            if (tile % 1000 == 259) tile = 256256;     // LayerNorm-folded launch: the four-wave kernel carries no fold code (r04: built in halves of a wave's columns, the residual + fold epilogue still spilled 196 registers beside the 256 AGPR accumulators and cost +80 ... +125 us per launch, and its mere presence slowed the unfolded path by 10-30 %: profiles/r04_experiments.txt), the 8-wave 256 x 256 tile does
             launch_gemm8(p, epilogue, tile / 32000, stream);
             return;
         }

@@ -24,7 +24,7 @@ echo "== launch-boundary micro-benchmark"; [ -x scripts/ubench/launch_chain ] &&
 echo "== rocprof PMC (HBM traffic, MFMA busy)"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $set | cut -d' ' -f1)
-  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$n -o pmc -- python "$R/bench.py" --steps 3 --warmup 1 --preheat 0 --no-matrix --no-cpu-baseline --no-roofline --no-host-api > /tmp/pmc_${TAG}_$n.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$n -o pmc -- python "$R/bench.py" --steps 3 --warmup 1 --preheat 0 --no-matrix --no-cpu-baseline --no-roofline --no-host-api --no-rates > /tmp/pmc_${TAG}_$n.log 2>&1)
 done
 python - <<PY | tee gpurun_out/${TAG}_pmc_traffic_and_mfma_busy.txt
 import csv, glob, collections, json, sys
@@ -43,6 +43,10 @@ for k in acc:
     out[k] = {"fetch_kb_raw": fs, "write_kb_raw": ws, "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0, "launches": cnt[(k, "FETCH_SIZE")]}
     print("%-60s FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  -> HBM bytes/launch (fetch x2) %.3e  [%d launches]" % (k[:60], fs, ws, out[k]["hbm_bytes_per_launch"], cnt[(k, "FETCH_SIZE")]))
 import bench
+# whole step: every launch of the PMC run belongs to one of its (1 warm-up + 3 timed) steps (--no-rates --preheat 0), except the load-time fold_kernel
+tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items() if "fold_kernel" not in k)
+out["_whole_step_hbm_bytes"] = tot / 4.0
+print("whole step: %.3e HBM bytes (sum over every launch of a step; 4 steps in the PMC run)" % out["_whole_step_hbm_bytes"])
 out["_kernel_src_sha16"] = bench.kernel_source_sha16()      # bench.py reports roofline.traffic only while the kernel sources are these
 out["_config"] = "b32_q4_0_b256"
 json.dump(out, open("gpurun_out/${TAG}_pmc_traffic.json", "w"), indent=1)
