@@ -537,7 +537,10 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
             const auto & hp = ctx->vision_hparams;
             const int G = hp.image_size / hp.patch_size;
             const long rows = (long)B * (G * G + 1);
-            split = hp.hidden_size >= 1024 ? (rows >= 2000 && rows <= 8400) : (rows >= 800 && rows <= 3300);
+            // With the text tower of the same step on a second stream (bench.py's two-tower cells) a third chain only helps the wide
+            // model: 32 + 32 ViT-B/32 59.9 k -> 58.3 k emb/s (-2.7 %, as much as 32 images alone gain), 32 + 32 ViT-L/14 7.98 k -> 8.38 k (+5 %).
+            // So the narrow models split only where the gain is ~6 % (48-64 images), the wide ones from 8 images.
+            split = hp.hidden_size >= 1024 ? (rows >= 2000 && rows <= 8400) : (rows >= 2000 && rows <= 3300);
         }
     }
     int ways = split ? std::min(ctx->split_ways, B) : 1;

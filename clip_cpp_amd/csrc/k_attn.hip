@@ -282,7 +282,9 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
     if constexpr (QB == 2) {
         const int npair = nqb >> 1;
         for (int u = slot; u < npair; u += nslot) attn_blocks<NT, DKS, DT, 2>(t, 2 * u);
-        if ((nqb & 1) && slot == npair % nslot) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
+        // the odd last block: its wave rotates with the workgroup index — T = 257 is 8 pairs + 1 block, and with the extra block always on
+        // wave npair % 4 the SIMD that hosts that wave of BOTH co-resident workgroups carries 10 blocks against 8 on the other three
+        if ((nqb & 1) && slot == (npair + (int)blockIdx.x) % nslot) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
     } else {
         for (int qb = slot; qb < nqb; qb += nslot) attn_blocks<NT, DKS, DT, 1>(t, qb);
     }
