@@ -107,7 +107,8 @@ bool ensure_panel(clip_ctx * ctx, size_t halfs) {
     return true;
 }
 
-LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows) {
+// res: this layer's four entries of the resident-panel table (resident_panels below), or null
+LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows, const half_t * const * res = nullptr) {
     LayerPanels lp;
     const DevWeight * ws[4] = {&l.qkv, &l.o, &l.ff1, &l.ff2};
     const half_t ** slot[4] = {&lp.qkv, &lp.o, &lp.ff1, &lp.ff2};
@@ -115,12 +116,16 @@ LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows) {
     half_t * jo[4];
     int nj = 0;
     size_t need = 0;
-    for (int i = 0; i < 4; i++)
-        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true))) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
+    bool todo[4];
+    for (int i = 0; i < 4; i++) {
+        if (res && res[i]) { *slot[i] = res[i]; todo[i] = false; continue; }       // kept from the first large batch: nothing to dequantise
+        todo[i] = ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true));
+        if (todo[i]) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
+    }
     if (!need || !ensure_panel(ctx, need)) return lp;
     size_t off = 0;
     for (int i = 0; i < 4; i++)
-        if (ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true))) {
+        if (todo[i]) {
             jw[nj] = ws[i];
             jo[nj] = ctx->w16_panel + off;
             *slot[i] = jo[nj];
@@ -274,14 +279,15 @@ bool run_layers_skinny_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h
 
 // L x { LN1, QKV, attention, out-proj(+res), LN2, FFN-up(+act), FFN-down(+res) }   (clip.cpp:1342-1423 / :1064-1143)
 bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
-                const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid, bool prune_last) {
+                const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid, bool prune_last,
+                const half_t * const * resp = nullptr) {
     hipStream_t s = ctx->stream;
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
     for (size_t li = 0; li < tw.layers.size(); li++) {
         const DevLayer & l = tw.layers[li];
-        const LayerPanels lp = dequant_layer(ctx, l, rows);
+        const LayerPanels lp = dequant_layer(ctx, l, rows, resp ? resp + 4 * li : nullptr);
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
             launch_layernorm(x, h, nullptr, 1, l.ln1_w, l.ln1_b, eps, rows, h, xn, h, nullptr, 0, s);
@@ -322,7 +328,7 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
 // Precondition: xn = fp16(x * ln1_w of layer 0) and stats = ONE slot per row over all h columns (launch_layernorm_prep / launch_text_embed).
 bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, int ff, float eps, int nseq, int T_uniform,
                      const int * d_seq_start, int max_len, bool causal, float * x, half_t * xn, half_t * qkv, half_t * att, half_t * mid,
-                     float2 * stats, int stats_stride, float * mu, bool prune_last) {
+                     float2 * stats, int stats_stride, float * mu, bool prune_last, const half_t * const * ff2p = nullptr) {
     hipStream_t s = ctx->stream;
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
@@ -343,7 +349,7 @@ bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int n
     };
     for (size_t li = 0; li < tw.layers.size(); li++) {
         const DevLayer & l = tw.layers[li];
-        const LayerPanels lp = dequant_layer(ctx, l, rows);
+        const LayerPanels lp = dequant_layer(ctx, l, rows, ff2p ? ff2p + 4 * li : nullptr);
         GemmParams p;
         p.M = rows; p.W = l.qkv; p.out = qkv; p.ldc = 3 * h; p.w16_pre = lp.qkv;
         p.qscale = qscale; p.qcols = h;   // Q = (W_q LN(x) + b_q) / sqrt(d_head): scale after bias (clip.cpp:1363)
@@ -402,6 +408,54 @@ bool pooled_tail(clip_ctx * ctx, const DevLayer & l, int n, int h, int ff, float
     p2.A = midp; p2.lda = ff; p2.M = n; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = xp; p2.ldc = h; p2.resid = xp;
     gemm(ctx, "gemm_ffn_down_pooled", p2, EPI_RESID_F32);
     return true;
+}
+
+// RESIDENT fp16 panels of block-quantised weights (round 4; profiles/r04_experiments.txt section 9): the FFN-down weight where the 8-wave
+// kernel on a panel beats the fused-dequant 4-wave kernel but a per-layer dequantisation launch would cost more than it gains (K >= 2048
+// and >= 200 tiles of 160 x 256 — ViT-B/32 at batch 256: 75.9 -> 71.7 us per launch, +1.0 ... +1.5 % on the BASELINE configuration on four
+// boxes; 57 MB, built on the first such batch).  Measured and NOT done: panels for all four weights of such a layer lose 2.3 % (the K = 768
+// GEMMs are slower on fp16 weights and everything slows down with the 4 x larger weight stream, as round 2 found); keeping the panels that
+// dequant_layer() rebuilds per layer at M >= 32768 (ViT-L/14 q5_1 batch 128: 606 MB) saves the 16 us launches but the GEMMs then read
+// cold fp16 weights from HBM instead of a panel that is hot in L2 / Infinity Cache: 4779 vs 4781 img/s.
+// Table entry 4 * layer + {0 q/k/v, 1 out, 2 FFN-up, 3 FFN-down}; null = multiply the quantised planes.  Built outside graph captures.
+const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int which, int rows) {
+    if (!ctx->resident_panels_on || tw.layers.empty()) return nullptr;
+    const DevLayer & l0 = tw.layers[0];
+    const DevWeight * w0[4] = {&l0.qkv, &l0.o, &l0.ff1, &l0.ff2};
+    unsigned want = 0;
+    (void)w0;
+    if (l0.ff2.wtype != W_F16 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
+    if (!want) return nullptr;
+    auto & tab = ctx->res_panels[which];
+    if ((ctx->res_panel_mask[which] & want) == want && tab.size() == 4 * tw.layers.size()) return tab.data();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &cs);
+    if (cs != hipStreamCaptureStatusNone) return (ctx->res_panel_mask[which] && tab.size() == 4 * tw.layers.size()) ? tab.data() : nullptr;
+    want |= ctx->res_panel_mask[which];
+    (void)hipStreamSynchronize(ctx->stream);                   // (re)build: nothing may still read the old table
+    if (ctx->res_panel_buf[which]) (void)hipFree(ctx->res_panel_buf[which]);
+    ctx->res_panel_buf[which] = nullptr;
+    ctx->res_panel_mask[which] = 0;
+    tab.clear();
+    size_t halfs = 0;
+    for (const DevLayer & l : tw.layers) {
+        const DevWeight * ws[4] = {&l.qkv, &l.o, &l.ff1, &l.ff2};
+        for (int i = 0; i < 4; i++) if (want >> i & 1) halfs += (size_t)ws[i]->Npad * ws[i]->Kpad;
+    }
+    if (hipMalloc((void **)&ctx->res_panel_buf[which], halfs * sizeof(half_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    size_t off = 0;
+    for (const DevLayer & l : tw.layers) {
+        const DevWeight * ws[4] = {&l.qkv, &l.o, &l.ff1, &l.ff2};
+        for (int i = 0; i < 4; i++) {
+            if (!(want >> i & 1)) { tab.push_back(nullptr); continue; }
+            half_t * o = ctx->res_panel_buf[which] + off;
+            launch_dequant(&ws[i], &o, 1, ctx->stream);
+            tab.push_back(o);
+            off += (size_t)ws[i]->Npad * ws[i]->Kpad;
+        }
+    }
+    ctx->res_panel_mask[which] = want;
+    return tab.data();
 }
 
 // The fold pays where the GEMMs run two workgroups per CU (k_gemm.hip, k_gemm_ring.hip): the statistics prologue and the xg / statistics
@@ -698,8 +752,8 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
         launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
         if (!run_layers_skinny(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.qkv, st.att, st.mid)) return false;
     } else if (fold) {
-        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr, prune)) return false;
-    } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, prune)) return false;
+        if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr, prune, resident_panels(ctx, V, 0, rows))) return false;
+    } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, prune, resident_panels(ctx, V, 0, rows))) return false;
     // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
     if (prune) {
         if (!pooled_tail(ctx, V.layers.back(), Bc, h, ff, hp.eps, x, st.att, nullptr, T, st.xp, st.ap, st.xnp, st.midp)) return false;
@@ -880,8 +934,8 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
             launch_row_stats(x, h, rows, h, ctx->sk_stats, s);
             if (!run_layers_skinny(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, qkv, att, mid)) return false;
         } else if (fold) {
-            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride, ctx->ln_fold_centre ? mu : nullptr, prune)) return false;
-        } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, prune)) return false;
+            if (!run_layers_fold(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, stats, st_stride, ctx->ln_fold_centre ? mu : nullptr, prune, resident_panels(ctx, Tw, 1, rows))) return false;
+        } else if (!run_layers(ctx, Tw, rows, h, nh, ff, hp.eps, n_texts, 0, seq, max_len, true, x, xn, qkv, att, mid, prune, resident_panels(ctx, Tw, 1, rows))) return false;
         // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
         if (prune) {    // ... and so is everything behind the last layer's attention: out-projection + FFN on the n_texts last-token rows only
             if (!pooled_tail(ctx, Tw.layers.back(), n_texts, h, ff, hp.eps, x, att, last, 1, xp, ap, xnp, midp)) return false;

@@ -581,6 +581,8 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         const char * e = getenv("CLIP_AMD_LNFOLD");
         ctx->ln_fold = !(e && e[0] == '0');
         ctx->ln_fold_force = e && e[0] == '2';       // tuning: fold even where forward.cpp fold_pays() says the LayerNorm launches are cheaper
+        const char * e2 = getenv("CLIP_AMD_RESIDENT_PANELS");
+        ctx->resident_panels_on = !(e2 && e2[0] == '0');
         const char * ep = getenv("CLIP_AMD_PRUNE_LAST");
         ctx->prune_last = !(ep && ep[0] == '0');
         const char * ec = getenv("CLIP_AMD_LNFOLD_CENTRE");
@@ -662,6 +664,7 @@ void free_model(clip_ctx * ctx) {
         if (ctx->pre_buf) (void)hipFree(ctx->pre_buf);
         free_preprocess_slots(ctx);
         if (ctx->w16_panel) (void)hipFree(ctx->w16_panel);
+        for (auto * b : ctx->res_panel_buf) if (b) (void)hipFree(b);
         if (ctx->sk_stats) (void)hipFree(ctx->sk_stats);
         if (ctx->sk_ws) (void)hipFree(ctx->sk_ws);
         if (ctx->sk_cnt) (void)hipFree(ctx->sk_cnt);

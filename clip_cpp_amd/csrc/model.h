@@ -159,6 +159,12 @@ struct clip_ctx {
     // fp16 panels of one layer's block-quantised weights for the large-M GEMM (k_gemm8.hip); grown on demand, re-filled per layer
     clipamd::half_t * w16_panel = nullptr;
     size_t w16_panel_halfs = 0;
+    // RESIDENT fp16 panels of block-quantised weights (forward.cpp resident_panels; round 4), per tower ([0] vision, [1] text): built on the
+    // first batch that wants them, entry 4 * layer + {0 q/k/v, 1 out, 2 FFN-up, 3 FFN-down}, null = multiply the quantised planes.
+    clipamd::half_t * res_panel_buf[2] = {nullptr, nullptr};
+    std::vector<const clipamd::half_t *> res_panels[2];
+    unsigned res_panel_mask[2] = {0, 0};      // which of the four weights the table holds (bit = index above)
+    bool resident_panels_on = true;           // CLIP_AMD_RESIDENT_PANELS=0: per-layer dequantisation launches / fused kernels only (A/B)
 
     // profiling (HIP events on the ctx stream)
     bool profiling = false;

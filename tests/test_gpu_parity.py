@@ -314,6 +314,35 @@ def test_last_layer_on_pooled_rows_only_matches_the_full_row_form(gpu, fixture_c
     np.testing.assert_allclose(got_t, ref_t, atol=atol)
 
 
+def test_resident_ffn_down_panels_do_not_change_a_bit(gpu, fixture_cache, monkeypatch):
+    """Round 4: at ViT-B/32 batch 256 the FFN-down GEMM (12800 x 768 x 3072) runs on the 8-wave kernel over a RESIDENT fp16 panel of the
+    q4_0 weight (forward.cpp resident_panels) instead of the fused-dequant 4-wave kernel.  Same dequantised values, same MFMA, same k
+    order: the embeddings must be bit-identical to CLIP_AMD_RESIDENT_PANELS=0, on the first call (panels built) and the second."""
+    torch = pytest.importorskip("torch")
+    p = fixtures.cached_model(fixture_cache, "b32", "q4_0", text=False, vision=True)
+    imgs = torch.from_numpy(fixtures.synthetic_images(256, 224, seed=17)).cuda()
+
+    def run(clip):
+        out = torch.empty((256, 512), dtype=torch.float32, device="cuda")
+        clip.encode_images_device(imgs.data_ptr(), 256, out.data_ptr(), True)
+        clip.synchronize()
+        return out.cpu().numpy()
+
+    monkeypatch.setenv("CLIP_AMD_RESIDENT_PANELS", "0")
+    c0 = gpu.Clip(p, device=0)
+    want = run(c0)
+    c0.close()
+    monkeypatch.delenv("CLIP_AMD_RESIDENT_PANELS", raising=False)
+    c1 = gpu.Clip(p, device=0)
+    c1.profile(True)
+    first = run(c1)
+    rep = c1.profile_report(reset=True)
+    c1.profile(False)
+    assert any(k.startswith("gemm8_kernel") and "ffn_down" in k for k in rep), sorted(rep)      # the panel kernel carries FFN-down
+    assert np.array_equal(first, want) and np.array_equal(run(c1), want)
+    c1.close()
+
+
 @pytest.mark.parametrize("config,ftype,B", [("b32", "q4_0", 32), ("b32", "q4_0", 33), ("tiny14", "f16", 12), ("b32", "f16", 8)])
 def test_mid_size_batch_split_over_two_streams_is_the_two_half_batches(gpu, fixture_cache, monkeypatch, config, ftype, B):
     """Round 4: a device-resident call of 8-64 images runs as two half-batches on two streams (the context and its
