@@ -19,7 +19,7 @@
 // Scores are never materialised in HBM (the reference materialises [T,T,n_head*B] f32).
 // Everything that indexes registers (key tiles NT, head-dim k-steps DKS, output d tiles DT) is a template
 // parameter and the MFMA chains are unconditional: padded keys are masked to -inf / multiplied by zero.
-// T <= 288 for every d_head in {32,64,80,96} (all 224-px models and every text length); T <= 592 for d_head <= 64
+// T <= 288 for every d_head in {32,64,80,88,96,104} (all 224-px models and every text length); T <= 592 for d_head <= 64
 // (ViT-L/14 at 336 px: T = 577, 154.6 KB of LDS); longer sequences are rejected by the launcher.
 
 #include "kernels.h"
@@ -43,7 +43,7 @@ struct AttnParams {
 };
 
 // Everything a wave needs to process query blocks of one (sequence, head): LDS tiles, global Q / output rows.
-template <int NT, int DKS, int DT>
+template <int NT, int DKS, int DT>      // (DHR, the real head size when it is not DT * 16, is a parameter of the functions below)
 struct AttnTile {
     const half_t * Ks;
     const half_t * Vt;
@@ -53,14 +53,14 @@ struct AttnTile {
 };
 
 // QB consecutive 16-query blocks starting at block qb0 (blocks beyond the sequence are computed on clamped rows and not stored).
-template <int NT, int DKS, int DT, int QB>
+template <int NT, int DKS, int DT, int QB, int DHR = DT * 16>
 __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int qb0) {
     constexpr int DKP = DKS * 32;
     constexpr bool SWZ = NT > 18;
     constexpr int KSTRIDE = SWZ ? DKP : DKP + 8;
     constexpr int NPR = (NT + 1) / 2;
     constexpr int VSTRIDE = NPR * 32 + 8;
-    constexpr int DH = DT * 16;
+    constexpr int DH = DHR;                          // real head size (a multiple of 8): 88 / 104 leave the last 16-wide output tile half empty
     const int fq = t.fq, fg = t.fg, len = t.len;
     // Q fragments (MFMA B operand): query row qb*16+fq, d = kk*32 + fg*8 .. +7
     h8 qf[QB][DKS];
@@ -174,7 +174,8 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
             if (q < len) {
                 half_t * orow = t.Og + (size_t)q * t.h + fq;
 #pragma unroll
-                for (int dt = 0; dt < DT; dt++) orow[dt * 16] = (_Float16)(o[j][dt][r] * invr[r]);
+                for (int dt = 0; dt < DT; dt++)
+                    if (DHR == DT * 16 || dt * 16 + fq < DHR) orow[dt * 16] = (_Float16)(o[j][dt][r] * invr[r]);
             }
         }
     }
@@ -182,10 +183,11 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
 
 // NT  = number of 16-key tiles (>= ceil(max_len/16)); DKS = 32-wide k-steps over the head dim (dh <= 32*DKS);
 // DT = dh/16 output tiles.
-template <int NT, int DKS, int DT>
+template <int NT, int DKS, int DT, int DHR = DT * 16>
 // occupancy: short sequences (T <= 80: ViT-B/32 images, every text) are latency-bound — stage, one barrier, a handful of MFMAs — so 4
 // workgroups per CU (<= 128 VGPRs) instead of 2 hide twice the memory latency; long ones need the registers
 __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_kernel(const AttnParams p) {
+    static_assert(DHR % 8 == 0 && DHR <= DT * 16 && DHR > (DT - 1) * 16 && DHR <= DKS * 32, "head size: whole 16-byte chunks, DT output tiles, DKS k-steps");
     constexpr int DKP = DKS * 32;
     // Long sequences (NT > 18: 336-px models, T = 577) only fit the 160 KB LDS without the row padding: K rows are then
     // exactly 128 B with the 16-byte chunks XOR-swizzled by (key & 7) instead (same conflict-free ds_read_b128 pattern
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
     constexpr int KSTRIDE = SWZ ? DKP : DKP + 8;     // halfs per K row  (+16 B pad: spreads ds_read_b128 over banks)
     constexpr int NPR = (NT + 1) / 2;                // key-tile pairs = K=32 slices of the P.V contraction
     constexpr int VSTRIDE = NPR * 32 + 8;            // halfs per V^T row; (VSTRIDE/2) = 4*odd -> conflict-free ds_read_b64
-    constexpr int DH = DT * 16;
+    constexpr int DH = DHR;                          // real head size; V^T rows DH .. DT*16-1 (88 / 104) are zeroed below and never stored
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half_t * Ks = (half_t *)smem_raw;                // [NT*16][KSTRIDE]
     half_t * Vt = Ks + NT * 16 * KSTRIDE;            // [DH][VSTRIDE]
@@ -266,6 +268,10 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
                 }
             }
         }
+        if constexpr (DHR < DT * 16) {               // the padding rows of V^T feed MFMAs whose outputs are dropped: keep them finite
+            for (int i = tid; i < (DT * 16 - DHR) * (NPR * 16); i += 256)
+                *(uint32_t *)(Vt + (DHR + i / (NPR * 16)) * VSTRIDE + 2 * (i % (NPR * 16))) = 0u;
+        }
     }
     __syncthreads();
 
@@ -274,50 +280,50 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
 
     // Query blocks are processed in PAIRS where the register budget allows (QB = 2: every K / V^T fragment read from LDS
     // feeds two MFMAs, halving the LDS traffic that bounds this kernel at T = 257), the odd last block alone.
-    constexpr int QB = (NT >= 7 && NT <= 18) ? 2 : 1;
+    constexpr int QB = (NT >= 7 && NT <= 18 && DT <= 6) ? 2 : 1;      // (d_head 104: 7 output tiles + 4 k-steps do not leave registers for block pairs)
     const AttnTile<NT, DKS, DT> t{Ks, Vt, Qg, p.out + (size_t)row0 * p.h + head * DH, ld, p.h, len, p.causal, fq, fg};
     // gridDim.y workgroups share one (sequence, head): each stages K / V^T itself and takes every gridDim.y-th set of four work units
     // (few sequences x heads and many query blocks — one ViT-L/14 image is 16 workgroups of 17 query blocks otherwise)
     const int slot = wave + 4 * blockIdx.y, nslot = 4 * gridDim.y;
     if constexpr (QB == 2) {
         const int npair = nqb >> 1;
-        for (int u = slot; u < npair; u += nslot) attn_blocks<NT, DKS, DT, 2>(t, 2 * u);
+        for (int u = slot; u < npair; u += nslot) attn_blocks<NT, DKS, DT, 2, DHR>(t, 2 * u);
         // the odd last block: its wave rotates with the workgroup index — T = 257 is 8 pairs + 1 block, and with the extra block always on
         // wave npair % 4 the SIMD that hosts that wave of BOTH co-resident workgroups carries 10 blocks against 8 on the other three
-        if ((nqb & 1) && slot == (npair + (int)blockIdx.x) % nslot) attn_blocks<NT, DKS, DT, 1>(t, nqb - 1);
+        if ((nqb & 1) && slot == (npair + (int)blockIdx.x) % nslot) attn_blocks<NT, DKS, DT, 1, DHR>(t, nqb - 1);
     } else {
-        for (int qb = slot; qb < nqb; qb += nslot) attn_blocks<NT, DKS, DT, 1>(t, qb);
+        for (int qb = slot; qb < nqb; qb += nslot) attn_blocks<NT, DKS, DT, 1, DHR>(t, qb);
     }
 }
 
-template <int NT, int DKS, int DT>
+template <int NT, int DKS, int DT, int DHR = DT * 16>
 void launch_inst(const AttnParams & p, int nseq, hipStream_t stream) {
     constexpr size_t smem = ((size_t)NT * 16 * (DKS * 32 + (NT > 18 ? 0 : 8)) + (size_t)DT * 16 * (((NT + 1) / 2) * 32 + 8)) * sizeof(half_t);
     static_assert(smem <= 160 * 1024, "attention tile does not fit the LDS");
     static unsigned long long lds_ok = 0;
-    if (smem > 64 * 1024) opt_in_dynamic_lds(attn_kernel<NT, DKS, DT>, smem, lds_ok);
+    if (smem > 64 * 1024) opt_in_dynamic_lds(attn_kernel<NT, DKS, DT, DHR>, smem, lds_ok);
     // query split: only where (sequence, head) pairs alone leave most CUs idle and a pair has more work units than one workgroup's 4 waves
-    constexpr int QB = (NT >= 7 && NT <= 18) ? 2 : 1;
+    constexpr int QB = (NT >= 7 && NT <= 18 && DT <= 6) ? 2 : 1;
     const int units = (NT + QB - 1) / QB;
     int qs = 1;
     if (nseq * p.n_head <= 64 && units > 4) qs = (units + 3) / 4 < 4 ? (units + 3) / 4 : 4;
-    hipLaunchKernelGGL((attn_kernel<NT, DKS, DT>), dim3(nseq * p.n_head, qs), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((attn_kernel<NT, DKS, DT, DHR>), dim3(nseq * p.n_head, qs), dim3(256), smem, stream, p);
 }
 
-template <int DKS, int DT>
+template <int DKS, int DT, int DHR = DT * 16>
 bool launch_nt(const AttnParams & p, int nseq, int nt, hipStream_t stream) {
-    if (nt <= 1) launch_inst<1, DKS, DT>(p, nseq, stream);
-    else if (nt <= 2) launch_inst<2, DKS, DT>(p, nseq, stream);
-    else if (nt <= 3) launch_inst<3, DKS, DT>(p, nseq, stream);
-    else if (nt <= 4) launch_inst<4, DKS, DT>(p, nseq, stream);
-    else if (nt <= 5) launch_inst<5, DKS, DT>(p, nseq, stream);
-    else if (nt <= 7) launch_inst<7, DKS, DT>(p, nseq, stream);
-    else if (nt <= 10) launch_inst<10, DKS, DT>(p, nseq, stream);
-    else if (nt <= 14) launch_inst<14, DKS, DT>(p, nseq, stream);
-    else if (nt <= 17) launch_inst<17, DKS, DT>(p, nseq, stream);
-    else if (nt <= 18) launch_inst<18, DKS, DT>(p, nseq, stream);
+    if (nt <= 1) launch_inst<1, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 2) launch_inst<2, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 3) launch_inst<3, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 4) launch_inst<4, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 5) launch_inst<5, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 7) launch_inst<7, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 10) launch_inst<10, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 14) launch_inst<14, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 17) launch_inst<17, DKS, DT, DHR>(p, nseq, stream);
+    else if (nt <= 18) launch_inst<18, DKS, DT, DHR>(p, nseq, stream);
     else if constexpr (DKS == 2) {
-        if (nt <= 37) launch_inst<37, DKS, DT>(p, nseq, stream);   // 336-px ViT-L/14: T = 577
+        if (nt <= 37) launch_inst<37, DKS, DT, DHR>(p, nseq, stream);   // 336-px ViT-L/14: T = 577
         else return false;
     } else return false;
     return true;
@@ -343,7 +349,9 @@ bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform,
     case 32: return launch_nt<1, 2>(p, nseq, nt, stream);
     case 64: return launch_nt<2, 4>(p, nseq, nt, stream);
     case 80: return launch_nt<3, 5>(p, nseq, nt, stream);
+    case 88: return launch_nt<3, 6, 88>(p, nseq, nt, stream);      // ViT-g/14 (hidden 1408, 16 heads)
     case 96: return launch_nt<3, 6>(p, nseq, nt, stream);
+    case 104: return launch_nt<4, 7, 104>(p, nseq, nt, stream);    // ViT-bigG/14 (hidden 1664, 16 heads)
     }
     return false;
 }

@@ -357,13 +357,13 @@ bool kv_u32(const GgufFile & g, const std::string & key, int32_t & out, std::str
 
 // What the kernels support, checked at load time so that an unsupported model fails HERE with a clear message instead of loading
 // and then producing garbage or failing at the first encode: LayerNorm holds a row in <= 8 x 256 floats; epilogues
-// store 4 columns per lane; the attention kernel is instantiated for d_head in {32, 64, 80, 96} and <= 592 (d_head <= 64) or 288 keys.
+// store 4 columns per lane; the attention kernel is instantiated for d_head in {32, 64, 80, 88, 96, 104} and <= 592 (d_head <= 64) or 288 keys.
 std::string kernel_limits(const char * tower, int hidden, int n_head, int proj, int seq_len) {
     char buf[192];
     const int dh = hidden / n_head;
     if (hidden > 2048) { snprintf(buf, sizeof buf, "unsupported %s hparams: hidden_size %d > 2048", tower, hidden); return buf; }
     if (proj <= 0 || proj % 4) { snprintf(buf, sizeof buf, "unsupported %s hparams: projection_dim %d is not a multiple of 4", tower, proj); return buf; }
-    if (dh != 32 && dh != 64 && dh != 80 && dh != 96) { snprintf(buf, sizeof buf, "unsupported %s hparams: head size %d (supported: 32, 64, 80, 96)", tower, dh); return buf; }
+    if (dh != 32 && dh != 64 && dh != 80 && dh != 88 && dh != 96 && dh != 104) { snprintf(buf, sizeof buf, "unsupported %s hparams: head size %d (supported: 32, 64, 80, 88, 96, 104)", tower, dh); return buf; }
     const int max_len = dh <= 64 ? 592 : 288;
     if (seq_len > max_len) { snprintf(buf, sizeof buf, "unsupported %s hparams: %d tokens per sequence > %d (head size %d)", tower, seq_len, max_len, dh); return buf; }
     return std::string();

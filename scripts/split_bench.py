@@ -16,9 +16,11 @@ for spec in models:
     arch, ftype = spec.split(":")
     path = synth.cached_model(cache, arch, ftype, text=False, vision=True, seed=1234)
     batches = (2, 4, 8, 16, 24, 32, 48, 64, 96, 128) if arch == "b32" else (2, 4, 8, 16, 32)
+    if os.environ.get("SPLIT_BENCH_BATCHES"):
+        batches = tuple(int(v) for v in os.environ["SPLIT_BENCH_BATCHES"].split(","))
     for B in batches:
         row = []
-        for split in ("0,0", "2,128,2", "2,128,3", "2,128,4"):
+        for split in ("0,0", "2,4096,2", "2,4096,3", "2,4096,4"):
             os.environ["CLIP_AMD_SPLIT"] = split
             clip = clip_cpp_amd.Clip(path, verbosity=0, device=0)
             S, proj = clip.vision_config["image_size"], clip.vision_config["projection_dim"]
@@ -31,7 +33,7 @@ for spec in models:
                 while time.perf_counter() - t0 < 0.3:
                     clip.encode_images_device(imgs.data_ptr(), B, out.data_ptr(), True)
                     torch.cuda.synchronize()
-                reps = 300 if arch == "b32" else 60
+                reps = (300 if B <= 128 else 60) if arch == "b32" else 60
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     clip.encode_images_device(imgs.data_ptr(), B, out.data_ptr(), True)

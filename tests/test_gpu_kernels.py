@@ -257,7 +257,9 @@ def attention_ref(qkv, nseq, T, h, nh, causal):
 
 @pytest.mark.parametrize("cfg", [(3, 17, 64, 2, 0), (2, 50, 768, 12, 0), (2, 257, 1024, 16, 0), (1, 257, 1280, 16, 0),
                                  (5, 9, 512, 8, 1), (2, 77, 512, 8, 1), (1, 1, 64, 2, 1), (1, 64, 128, 2, 0), (1, 288, 128, 2, 1),
-                                 (2, 577, 1024, 16, 0), (1, 300, 128, 2, 0), (1, 592, 64, 1, 1)])   # 336-px ViT-L/14: T = 577
+                                 (2, 577, 1024, 16, 0), (1, 300, 128, 2, 0), (1, 592, 64, 1, 1),   # 336-px ViT-L/14: T = 577
+                                 (2, 257, 1408, 16, 0), (3, 50, 176, 2, 0), (2, 77, 176, 2, 1),     # d_head 88 (ViT-g/14)
+                                 (1, 257, 1664, 16, 0), (3, 17, 208, 2, 0), (2, 77, 208, 2, 1), (1, 288, 104, 1, 1)])   # d_head 104 (ViT-bigG/14)
 def test_attention_vs_reference(L, cfg):
     nseq, T, h, nh, causal = cfg
     rng = np.random.default_rng(sum(cfg))

@@ -314,6 +314,23 @@ def test_last_layer_on_pooled_rows_only_matches_the_full_row_form(gpu, fixture_c
     np.testing.assert_allclose(got_t, ref_t, atol=atol)
 
 
+@pytest.mark.parametrize("config,ftype", [("g88", "f16"), ("g88", "q4_0"), ("g104", "q5_1"), ("g104", "f16")])
+def test_head_sizes_88_and_104_end_to_end(gpu, fixture_cache, config, ftype):
+    """ViT-g/14 (d_head 88) and ViT-bigG/14 (d_head 104) head sizes, which the reference's generic graph accepts (clip.cpp:463-583, 1366-1388)
+    and this library rejected at load until round 4: the attention kernel pads the last 16-wide output tile.  Vision tower against the oracle,
+    5 images (T = 5: the small-M path) and 40 (T = 5 x 40 rows / T = 17: the tiled path)."""
+    p = fixtures.cached_model(fixture_cache, config, ftype, text=False, vision=True)
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    S = fixtures.CONFIGS[config]["v"]["S"]
+    for n in (5, 40):
+        imgs = fixtures.synthetic_images(n, S, seed=40 + n)
+        got = clip.encode_images(imgs)
+        want = orc.image_batch_encode(imgs, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=ref.host_cores())
+        d = one_minus_cos(got, want)
+        assert np.all(np.isfinite(got)) and np.all(d <= TOL[ftype]), (config, ftype, n, float(d.max()))
+    clip.close()
+
+
 def test_resident_ffn_down_panels_do_not_change_a_bit(gpu, fixture_cache, monkeypatch):
     """Round 4: at ViT-B/32 batch 256 the FFN-down GEMM (12800 x 768 x 3072) runs on the 8-wave kernel over a RESIDENT fp16 panel of the
     q4_0 weight (forward.cpp resident_panels) instead of the fused-dequant 4-wave kernel.  Same dequantised values, same MFMA, same k
