@@ -33,7 +33,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     ws = d["whole_step_roofline"]
     assert ws["bound"] in ("mfma", "hbm") and 0 < ws["frac"] <= 1.0 and ws["algorithmic_flops_per_step"] > 0
     assert d["host_api_images_per_s"] > 0 and d["config"]["name"] == "custom"
-    assert "traffic" in rf and "traffic_note" in rf and 0 < rf["frac_8d"] <= 1.0
+    assert "traffic" in rf and "traffic_note" in rf and 0 < rf["frac_8d"] <= 1.0 and rf["frac_8d"] == rf["frac"]       # frac IS the SURVEY 8(d) view since round 4
+    assert d["host_api_u8_images_per_s"] > 0 and d["host_api_u8_images_per_s_4x_batch_per_call"] > 0                   # the raw-u8 entry point beside the f32 one
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"] and d["python_gc"].startswith("disabled") and d["self_launched"] is False
+    assert ws["executed_flops_per_step"] <= ws["algorithmic_flops_per_step"]
 
 
 def test_bench_collective_path_runs_with_one_rank():
