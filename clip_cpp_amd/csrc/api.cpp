@@ -217,15 +217,20 @@ bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct 
 // raw u8 images -> embeddings with the resize/crop/normalise on the GPU (bit-identical to clip_image_preprocess):
 // ships <= 3 B/pixel of the ORIGINAL image instead of 12 B/pixel of the resized one and takes the double-precision
 // resampling (the dominant host cost of benchmark.cpp / zsl.cpp style callers) off the CPU.
-// n raw images -> d_out [n][proj] on ctx's device, queued on ctx->stream (chunks of <= 256 images / ~512 MB of raw pixels; a call of
-// several chunks double-buffers the staging so that chunk c + 1's host copy and H2D run under chunk c's forward pass).
+// n raw images -> d_out [n][proj] on ctx's device, queued on ctx->stream.
 static bool encode_u8_to_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out, bool normalize) {
     const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
     const size_t per = (size_t)S * S * 3;
     (void)hipSetDevice(ctx->device);
     bool ok = true;
-    int b0 = 0, chunk_idx = 0;
-    const bool multi_chunk = n > 256;
+    int b0 = 0, piece_idx = 0;
+    // Two granularities (as the f32 host pipeline, host_pipeline.cpp).  FORWARD chunks of <= 256 images / ~512 MB of raw pixels: one vision
+    // forward each.  STAGING pieces of <= 128 images (CLIP_AMD_U8_PIECE) inside a chunk: the host fills pinned slot (piece % 4) while the previous pieces' H2D
+    // (copy stream) and preprocessing kernels run, so only the first piece's host copy and the last piece's H2D are exposed before the
+    // forward — and the pieces of chunk c + 1 are staged under chunk c's forward.  The preprocessed f32 images of a chunk land in ONE
+    // buffer (io_in): the kernels that write it for chunk c + 1 are stream-ordered behind the forward that reads it for chunk c.
+    static const int piece_max = [] { const char * e = getenv("CLIP_AMD_U8_PIECE"); const int v = e ? atoi(e) : 128; return v < 8 ? 8 : v > 256 ? 256 : v; }();   // tuning
+    const bool pipelined = n > piece_max;
     while (b0 < n && ok) {
         int bc = 0;
         size_t bytes = 0;
@@ -237,12 +242,19 @@ static bool encode_u8_to_device(clip_ctx * ctx, const clip_image_u8 * imgs, int 
             fprintf(stderr, "clip_amd_image_batch_encode_u8: out of device memory\n");
             return false;
         }
-        // one chunk: the single staging blob; several: double-buffered staging, no synchronisation between chunks — the host fills the
-        // next chunk's pinned blob and the copy stream ships it under this chunk's forward pass (preprocess.cpp)
-        ok = ok && preprocess_batch_device(ctx, imgs + b0, bc, (float *)ctx->io_in, multi_chunk ? (chunk_idx & 1) : -1);
+        for (int p0 = 0; p0 < bc && ok;) {
+            int pn = 0;
+            size_t pbytes = 0;
+            while (p0 + pn < bc && pn < (pipelined ? piece_max : bc) && (pn == 0 || pbytes < ((size_t)128 << 20))) {
+                pbytes += (size_t)3 * (size_t)std::max(0, imgs[b0 + p0 + pn].nx) * (size_t)std::max(0, imgs[b0 + p0 + pn].ny);
+                pn++;
+            }
+            ok = ok && preprocess_batch_device(ctx, imgs + b0 + p0, pn, (float *)ctx->io_in + (size_t)p0 * per, pipelined ? piece_idx : -1);
+            p0 += pn;
+            piece_idx++;
+        }
         ok = ok && vision_forward_device(ctx, (const float *)ctx->io_in, bc, d_out + (size_t)b0 * proj, normalize);
         b0 += bc;
-        chunk_idx++;
     }
     return ok;
 }

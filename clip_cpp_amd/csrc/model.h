@@ -139,10 +139,11 @@ struct clip_ctx {
     hipEvent_t ev_stream_switch = nullptr;   // orders a new stream behind the work queued on the previous one (clip_amd_set_stream)
     void * pre_buf = nullptr;        // device blob of the GPU preprocessing path (descriptors, taps, raw pixels, row buffer)
     size_t pre_bytes = 0;
-    // ... and its double-buffered form for calls of several chunks (clip_amd_image_batch_encode_u8 > 256 images): while chunk c is
-    // preprocessed and encoded, the host fills slot (c + 1) & 1 and the copy stream ships it (preprocess.cpp)
+    // ... and its ring of staging slots for calls of more than 128 images (clip_amd_image_batch_encode_u8): pieces of <= 128 images; while
+    // piece p is copied / preprocessed (and the previous chunk encoded), the host fills the next slot and the copy stream ships it (preprocess.cpp)
     struct PreSlot { void * pin = nullptr; size_t pin_bytes = 0; void * dev = nullptr; size_t dev_bytes = 0; hipEvent_t ev_h2d = nullptr, ev_done = nullptr; bool used = false; };
-    PreSlot pre_slot[2];
+    static constexpr int PRE_SLOTS = 4;       // = staging pieces per forward chunk: a whole chunk can be staged under the previous chunk's forward
+    PreSlot pre_slot[PRE_SLOTS];
     hipStream_t pre_copy_stream = nullptr;
     // split-K workspace of the GEMM (kernels.h GemmParams::sk_*): partial tiles + per-tile ticket counters (kept zero)
     float * sk_ws = nullptr;

@@ -153,10 +153,10 @@ void free_preprocess_slots(clip_ctx * ctx) {
 }
 
 // slot < 0: one staging blob, the stream is synchronised first (the blob of the previous call may still be in use), H2D on ctx->stream.
-// slot 0 / 1 (calls of several chunks, api.cpp encode_u8_to_device): double-buffered staging — the host fills pinned slot s while the
-// GPU still works on the other slot's chunk, the copy travels on a copy stream under that chunk's forward pass, and the only waits are
-// events (this slot's previous H2D before the host overwrites the pinned blob; its previous kernels before the copy overwrites the
-// device blob).  d_out may be the same buffer for every chunk: the kernels writing it are stream-ordered behind the forward reading it.
+// slot >= 0 (calls of more than one staging piece, api.cpp encode_u8_to_device): a ring of PRE_SLOTS staging slots — the host fills pinned slot s
+// while the GPU still works on the pieces in the other slots, the copy travels on a copy stream (under the previous chunk's forward
+// pass), and the only waits are events (this slot's previous H2D before the host overwrites the pinned blob; its previous kernels before
+// the copy overwrites the device blob).  d_out regions of one buffer: the kernels writing them are stream-ordered behind the forward reading it.
 bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, float * d_out, int slot) {
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
@@ -229,7 +229,7 @@ bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, 
     const size_t host_bytes = up(o_raw + raw_bytes), total = host_bytes + hbuf_floats * sizeof(float);
     (void)hipSetDevice(ctx->device);
     uint8_t * h = nullptr, * dv = nullptr;
-    clip_ctx::PreSlot * sl = slot >= 0 ? &ctx->pre_slot[slot & 1] : nullptr;
+    clip_ctx::PreSlot * sl = slot >= 0 ? &ctx->pre_slot[slot % clip_ctx::PRE_SLOTS] : nullptr;
     if (!sl) {
         (void)hipStreamSynchronize(ctx->stream);   // the pinned blob / device buffer of the previous call may still be in use
         if (!ensure_pinned(ctx, host_bytes)) { fprintf(stderr, "clip (hip): cannot pin %zu MB\n", host_bytes >> 20); return false; }
