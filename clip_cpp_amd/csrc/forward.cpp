@@ -586,7 +586,7 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
         if (ctx->split_max >= 0) split = B >= ctx->split_min && B <= ctx->split_max;           // CLIP_AMD_SPLIT
         else {
             // measured (profiles/r04_batch_split_sweep.txt, one forward vs two halves, hipGraph replay where it applies): ViT-B/32 q4_0
-            // +5.6 / +4.1 / +2.7 / +6.4 / +5.9 % at 16 / 24 / 32 / 48 / 64 images (800-3200 token rows), -3 ... -5 % at 4 / 8 / 96;
+            // +6.4 / +4.1 / +2.6 / +6.3 / +5.9 % at 16 / 24 / 32 / 48 / 64 images (800-3200 token rows), -3 ... -5 % at 4 / 8 / 96;
             // ViT-L/14 f16 +23 / +11 / +5 % at 8 / 16 / 32 images (2056-8224 rows), -2 % at 4.  3 and 4 parts are slower everywhere.
             const auto & hp = ctx->vision_hparams;
             const int G = hp.image_size / hp.patch_size;
