@@ -86,6 +86,39 @@ def test_rccl_binding_runs_on_one_device(clip_lib, fixture_cache, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_pair_call_through_rccl_on_one_device(clip_lib, fixture_cache, monkeypatch):
+    """clip_amd_encode_pair_device_multi with the REAL collective on one device (CLIP_AMD_MULTI_FORCE_RCCL=1: one replica, ncclCommInitAll,
+    a one-rank grouped ncclAllGather of the [images | texts] block): both towers on two streams (replica + sibling context), the gathered
+    buffer holds the image rows then the text rows, the host copies are the single-context results bit for bit."""
+    if clip_lib.device_count() < 1:
+        pytest.fail("GPU tier needs a HIP device")
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("CLIP_AMD_MULTI_FORCE_RCCL", "1")
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0", text=True, vision=True)
+    single = clip_lib.Clip(p, device=0)
+    multi = clip_lib.Clip(p, n_devices=1)
+    B, NT = 23, 31
+    imgs = fixtures.synthetic_images(B, 32, seed=8)
+    texts = fixtures.synthetic_token_ids(NT, seed=4, min_len=3, max_len=40)
+    want_i, want_t = single.encode_images(imgs), single.encode_texts(texts)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_ids = torch.from_numpy(np.concatenate(texts).astype(np.int32)).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        out_i, out_t = np.zeros((B, 32), np.float32), np.zeros((NT, 32), np.float32)
+        multi.encode_pair_device_multi([d_img.data_ptr()], B, [d_ids.data_ptr()], offs, True, out_i, out_t)
+        assert np.array_equal(out_i, want_i) and np.array_equal(out_t, want_t)
+    ptr = clip_lib.lib().clip_amd_gathered_embeddings(multi.ctx, 0)
+    t = torch.empty((B + NT, 32), dtype=torch.float32, device="cuda:0")
+    assert C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), t.numel() * 4, 3) == 0
+    assert np.array_equal(t.cpu().numpy(), np.concatenate([want_i, want_t]))
+    multi.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_rccl_all_gather_path_with_two_devices(clip_lib, fixture_cache):
     if clip_lib.device_count() < 2:
         pytest.skip("needs >= 2 visible HIP devices (the 1-GPU box runs the over-subscribed form above)")
