@@ -190,11 +190,13 @@ def file_type_id(ftype):
 
 def make_model(path, config="tiny", ftype="f32", text=True, vision=True, seed=1234, use_gelu=False,
                image_mean=(0.48145466, 0.4578275, 0.40821073), image_std=(0.26862954, 0.26130258, 0.27577711),
-               eps=1e-5, version=2, keep_master=False, dc=0.0):
+               eps=1e-5, version=2, keep_master=False, dc=0.0, spike=0.0):
     """Write a synthetic CLIP GGUF. Returns dict(name -> f32 master ndarray) if keep_master.
     dc != 0: residual-stream rows with a large common mode (|mean| / std ~ dc and drifting from layer to layer), the statistics the
     seeded N(0, 0.02^2) weights never produce: the vision pre-LN bias gets +dc (rows of std ~1), the text position embedding +0.03 dc
-    (rows of std ~0.03), and every out-projection / FFN-down bias a tenth of that — the LayerNorm-fold parity fixtures."""
+    (rows of std ~0.03), and every out-projection / FFN-down bias a tenth of that — the LayerNorm-fold parity fixtures.
+    spike != 0: "massive activation" channels as real CLIP ViT-L / H checkpoints have them — three fixed channels of the same tensors get
+    +spike (x the tower's scale) on top, so a handful of residual-stream channels sit tens of sigma away from the rest in every row."""
     cfg = CONFIGS[config] if isinstance(config, str) else config
     tid_file = file_type_id(ftype)
     kvs = [("general.architecture", "str", "clip"),
@@ -223,10 +225,12 @@ def make_model(path, config="tiny", ftype="f32", text=True, vision=True, seed=12
     master = {}
     for name, shape, kind in tensor_specs(cfg, text, vision):
         w = gen_tensor(name, shape, kind, seed)
-        if dc:
+        if dc or spike:
             tower_scale = 1.0 if name.startswith("v.") else 0.03
             if name in ("v.pre_ln.bias", "t.position_embd.weight"):
                 w = (w + dc * tower_scale).astype(np.float32)
+                if spike:
+                    w[..., [3, shape[-1] // 2 + 1, shape[-1] - 5]] += spike * tower_scale
             elif name.endswith("attn_out.bias") or name.endswith("ffn_up.bias"):      # (sic: "ffn_up" is fc2, the projection back to h)
                 w = (w + 0.1 * dc * tower_scale).astype(np.float32)
         if keep_master:
@@ -249,13 +253,13 @@ def make_model(path, config="tiny", ftype="f32", text=True, vision=True, seed=12
     return master if keep_master else None
 
 
-def cached_model(cache_dir, config="tiny", ftype="f32", text=True, vision=True, seed=1234, use_gelu=False, dc=0.0):
+def cached_model(cache_dir, config="tiny", ftype="f32", text=True, vision=True, seed=1234, use_gelu=False, dc=0.0, spike=0.0):
     os.makedirs(cache_dir, exist_ok=True)
-    tag = "%s_%s_%s%s_s%d%s%s.gguf" % (config, ftype, "t" if text else "", "v" if vision else "", seed, "_gelu" if use_gelu else "", ("_dc%g" % dc) if dc else "")
+    tag = "%s_%s_%s%s_s%d%s%s.gguf" % (config, ftype, "t" if text else "", "v" if vision else "", seed, "_gelu" if use_gelu else "", (("_dc%g" % dc) if dc else "") + (("_spk%g" % spike) if spike else ""))
     path = os.path.join(cache_dir, tag)
     if not os.path.exists(path):
         tmp = path + ".tmp%d" % os.getpid()
-        make_model(tmp, config, ftype, text, vision, seed, use_gelu, dc=dc)
+        make_model(tmp, config, ftype, text, vision, seed, use_gelu, dc=dc, spike=spike)
         os.replace(tmp, path)
     return path
 

@@ -406,14 +406,15 @@ def test_mid_size_batch_split_over_two_streams_is_the_two_half_batches(gpu, fixt
     assert np.all(one_minus_cos(halves, whole) <= 1e-6), one_minus_cos(halves, whole).max()
 
 
-@pytest.mark.parametrize("ftype,dc", [("f16", 6.0), ("q4_0", 6.0), ("f16", 20.0)])
-def test_layernorm_fold_under_a_large_common_mode_end_to_end(gpu, fixture_cache, monkeypatch, ftype, dc):
+@pytest.mark.parametrize("ftype,dc,spike", [("f16", 6.0, 0.0), ("q4_0", 6.0, 0.0), ("f16", 20.0, 0.0), ("f16", 4.0, 60.0), ("q8_0", 0.0, 80.0)])
+def test_layernorm_fold_under_a_large_common_mode_end_to_end(gpu, fixture_cache, monkeypatch, ftype, dc, spike):
     """a ViT-B/32-shaped model whose residual rows carry a common mode of |mean| / std >= ~5 that drifts from layer
     to layer (fixtures dc: pre-LN bias, position embedding, out-projection / FFN-down biases), both towers, against the oracle in the
     reference's numerics (normalise first: clip.cpp:1350-1355).  The default (fold with the operand centred on the previous LayerNorm's
     row mean) is held to TOL_MODEL like every other model-shape test, and to the error of the LayerNorm-launch form; the uncentred r03
     fold is measured beside it for the record (gpurun_out/)."""
-    p = fixtures.cached_model(fixture_cache, "b32", ftype, dc=dc)
+    # (spike: three "massive activation" channels tens of sigma away from the rest in every row, as real ViT-L / H checkpoints have them)
+    p = fixtures.cached_model(fixture_cache, "b32", ftype, dc=dc, spike=spike)
     orc = ref.OracleModel(p)
     imgs = fixtures.synthetic_images(6, 224, seed=31)
     texts = _ragged_text_batch(16, 77, seed=5)
@@ -431,13 +432,30 @@ def test_layernorm_fold_under_a_large_common_mode_end_to_end(gpu, fixture_cache,
         res[name] = (float(one_minus_cos(gi, want_i).max()), float(one_minus_cos(gt, want_t).max()))
     monkeypatch.delenv("CLIP_AMD_LNFOLD", raising=False)
     monkeypatch.delenv("CLIP_AMD_LNFOLD_CENTRE", raising=False)
-    line = "b32 %s dc=%g: max 1 - cos vs the oracle (images, texts): fold centred %.2e %.2e | fold r03 (uncentred) %.2e %.2e | LayerNorm launches %.2e %.2e" % (
-        (ftype, dc) + res["centred"] + res["uncentred"] + res["launches"])
+    line = "b32 %s dc=%g spike=%g: max 1 - cos vs the oracle (images, texts): fold centred %.2e %.2e | fold r03 (uncentred) %.2e %.2e | LayerNorm launches %.2e %.2e" % (
+        (ftype, dc, spike) + res["centred"] + res["uncentred"] + res["launches"])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r04_lnfold_centre_e2e.txt"), "a") as f:
         f.write(line + "\n")
-    assert res["centred"][0] <= TOL_MODEL[ftype] and res["centred"][1] <= TOL_MODEL_TEXT[ftype], line
     assert res["centred"][0] <= 2.0 * res["launches"][0] + 2e-6 and res["centred"][1] <= 2.0 * res["launches"][1] + 2e-6, line
+    if spike and ftype.startswith("q"):
+        # Massive-activation channels and a block-quantised file: ggml quantises the ACTIVATIONS to 8 bits in blocks of 32, so a
+        # spike costs the other 31 values of its block their resolution — the oracle's faithful mode moves ~1e-3 away from the ideal network on
+        # the text tower, in every GPU form alike (fold or not).  The GPU keeps fp16 activations: it must sit at the oracle's IDEAL mode, and
+        # the faithful oracle must be the outlier (distance to ideal >= 5 x the GPU's).
+        ideal_i = orc.image_batch_encode(imgs, normalize=True, mode=ref.MODE_IDEAL, n_threads=ref.host_cores())
+        ideal_t = np.stack([orc.text_encode(t, normalize=True, mode=ref.MODE_IDEAL, n_threads=ref.host_cores()) for t in texts])
+        clip = gpu.Clip(p, device=0)
+        gi, gt = clip.encode_images(imgs), clip.encode_texts(texts)
+        clip.close()
+        g_i, g_t = float(one_minus_cos(gi, ideal_i).max()), float(one_minus_cos(gt, ideal_t).max())
+        f_t = float(one_minus_cos(want_t, ideal_t).max())
+        with open(os.path.join(ROOT, "gpurun_out", "r04_lnfold_centre_e2e.txt"), "a") as f:
+            f.write("    ... against the oracle's IDEAL mode: GPU %.2e %.2e; the faithful oracle itself is %.2e away from ideal on the texts\n" % (g_i, g_t, f_t))
+        assert g_i <= 1e-4 and g_t <= 1e-4 and f_t >= 5.0 * g_t, (g_i, g_t, f_t)
+        assert res["centred"][0] <= TOL[ftype] and res["centred"][1] <= 2.0 * TOL[ftype], line       # documented contract, with the oracle's own noise doubled
+    else:
+        assert res["centred"][0] <= TOL_MODEL[ftype] and res["centred"][1] <= TOL_MODEL_TEXT[ftype], line
 
 
 @pytest.mark.parametrize("ftype", ["f16", "q4_0"])
