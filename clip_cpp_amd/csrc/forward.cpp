@@ -724,7 +724,7 @@ bool vision_stage_patch(clip_ctx * ctx, const VisionStage & st, const void * img
     pp.A = col; pp.lda = V.patch.Kpad; pp.M = n * Np; pp.W = V.patch; pp.out = x; pp.ldc = h;
     pp.Np = Np; pp.T = T; pp.pos = V.pos; pp.no_splitk = piece;
     gemm(ctx, "gemm_patch", pp, EPI_PATCH_F32);
-    launch_cls_rows(x, V.class_embd, V.pos, n, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
+    // (the class-token rows — class_embd + pos[0], clip.cpp:1315-1331 — are produced by the pre-LN launch of vision_stage_finish)
     return true;
 }
 
@@ -740,9 +740,13 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
     const bool fold = ctx->ln_fold && !V.layers.empty() && (ctx->ln_fold_force || fold_pays(V, rows));
     {
         ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
-        if (fold)   // pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
-            launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, st.xn, h, st.stats, s, ctx->ln_fold_centre ? st.mu : nullptr);
-        else launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
+        if (fold)   // class-token rows (:1315-1331) + pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
+            launch_layernorm_prep(x, h, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, x, h, V.layers[0].ln1_w, st.xn, h, st.stats, s, ctx->ln_fold_centre ? st.mu : nullptr,
+                                  V.class_embd, V.pos, T);
+        else {
+            launch_cls_rows(x, V.class_embd, V.pos, Bc, T, h, s);   // class token + pos[0] (clip.cpp:1315-1331)
+            launch_layernorm(x, h, nullptr, 1, V.pre_ln_w, V.pre_ln_b, hp.eps, rows, h, nullptr, 0, x, h, s);
+        }
     }
     // rows beyond the small-M path: the last layer's out-projection and FFN run on the Bc class-token rows only (pooled_tail)
     const bool prune = ctx->prune_last && !skinny && !V.layers.empty() && T > 1;

@@ -123,18 +123,20 @@ template <int NV>
 __global__ void __launch_bounds__(256) layernorm_prep_kernel(const float * x, int ldx, const float * __restrict__ w, const float * __restrict__ b,
                                                              float eps, int rows, int h, float * out32, int ld32,
                                                              const float * __restrict__ gnext, half_t * __restrict__ xg, int ldxg,
-                                                             float2 * __restrict__ stats, float * __restrict__ mu_out) {
+                                                             float2 * __restrict__ stats, float * __restrict__ mu_out,
+                                                             const float * __restrict__ cls, const float * __restrict__ pos0, int T) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const float * xr = x + (size_t)r * ldx;
+    const bool cls_row = cls != nullptr && r % T == 0;    // class-token row (reference clip.cpp:1315-1331): class_embd + pos[0], the sum cls_rows_kernel stores — here it never touches memory
     f4 v[NV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * 4;
         if (c < h) {
-            v[i] = *(const f4 *)(xr + c);
+            v[i] = cls_row ? *(const f4 *)(cls + c) + *(const f4 *)(pos0 + c) : *(const f4 *)(xr + c);
             sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         } else {
             v[i] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -561,11 +563,12 @@ void launch_text_embed(const int32_t * ids, const int * seq_start, int nseq, int
 }
 
 void launch_layernorm_prep(const float * x, int ldx, const float * w, const float * b, float eps, int rows, int h, float * out32, int ld32,
-                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream, float * mu_out) {
+                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream, float * mu_out,
+                           const float * class_embd, const float * pos0, int T) {
     if (rows <= 0) return;
     const dim3 grid((rows + 3) / 4), block(256);
 #define CLIPAMD_LNP(NV)                                                                                                             \
-    hipLaunchKernelGGL((layernorm_prep_kernel<NV>), grid, block, 0, stream, x, ldx, w, b, eps, rows, h, out32, ld32, gamma_next, xg, ldxg, stats, mu_out)
+    hipLaunchKernelGGL((layernorm_prep_kernel<NV>), grid, block, 0, stream, x, ldx, w, b, eps, rows, h, out32, ld32, gamma_next, xg, ldxg, stats, mu_out, class_embd, pos0, T > 0 ? T : 1)
     if (h <= 256) { CLIPAMD_LNP(1); }
     else if (h <= 512) { CLIPAMD_LNP(2); }
     else if (h <= 768) { CLIPAMD_LNP(3); }

@@ -205,7 +205,8 @@ void launch_layernorm(const float * x, int ldx, const int * in_rows, int in_row_
 // reference clip.cpp:1334-1339) written to out32 in the same launch; launch_text_embed with xg != null: y = the embedded rows.
 // mu_out != null: the centred form — xg = fp16((y - mean) gamma_next), mu_out[r] = mean (GemmParams::ln_mu of the first consumer).
 void launch_layernorm_prep(const float * x, int ldx, const float * w, const float * b, float eps, int rows, int h, float * out32, int ld32,
-                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream, float * mu_out = nullptr);
+                           const float * gamma_next, half_t * xg, int ldxg, float2 * stats, hipStream_t stream, float * mu_out = nullptr,
+                           const float * class_embd = nullptr, const float * pos0 = nullptr, int T = 0);   // class_embd != null: rows r % T == 0 are class_embd + pos0 (never loaded from x)
 
 // Multi-head self-attention softmax(QK^T)V (reference clip.cpp:1382-1388; causal for text :1101).
 // qkv: [rows][3h] fp16 with Q pre-scaled; sequences given by seq_start[nseq+1] (device) or, when
