@@ -571,7 +571,7 @@ bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * 
             (void)hipSetDevice(c->device);
         }
         clip_ctx * t = mc->twin[g];
-        c->sibling_busy = true;                      // the sibling carries the text tower: the vision half of this call is not split over it
+        struct Busy { clip_ctx * c; explicit Busy(clip_ctx * c_) : c(c_) { c->sibling_busy = true; } ~Busy() { c->sibling_busy = false; } } busy(c);   // the sibling carries the text tower: the vision half of this call is not split over it (reset on every exit path)
         void * sp = mc->send[g], * rp = mc->recv[g];
         size_t sb = mc->send_floats[g] * 4, rb = mc->recv_floats[g] * 4;
         const bool grew = sb < (size_t)per_dev * proj * 4 || rb < (size_t)G * per_dev * proj * 4;
@@ -590,7 +590,6 @@ bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * 
         if (ht > lt && !run_txt(g, t, lt, ht, s_txt)) okv[g] = 0;
         // join: the all-gather on the replica stream sees both towers
         if (hipEventRecord(mc->ev_join[g], t->stream) != hipSuccess || hipStreamWaitEvent(c->stream, mc->ev_join[g], 0) != hipSuccess) okv[g] = 0;
-        c->sibling_busy = false;
     };
     mc->replicas.run(G, work);
     for (int g = 0; g < G; g++)
