@@ -577,8 +577,9 @@ def main():
              "frac": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4)}
     if os.environ.get("CLIP_AMD_PRUNE_LAST", "1") != "0":
         whole["executed_flops_per_step"] = fl_step - pruned_flops(vc, tc, batch, [len(t) for t in texts])
+        whole["frac_executed"] = round(whole["executed_flops_per_step"] / (MFMA_F16_PEAK_TFLOPS * 1e12) / (ms_step * 1e-3), 4) if ws_bound == "mfma" else None
         whole["executed_note"] = ("the last layer's out-projection + FFN run on the pooled row of every sequence only (same embeddings); `frac` and "
-                                  "`achieved_tflops` use the SURVEY 8(d) algorithmic FLOPs, executed_flops_per_step is what the kernels multiply")
+                                  "`achieved_tflops` use the SURVEY 8(d) algorithmic FLOPs, executed_flops_per_step is what the kernels multiply and frac_executed the MFMA fraction of THAT")
 
     roofline = None
     kernels = None
@@ -763,7 +764,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload, "name": args.config if not custom else "custom",
                        "weights": "%s %s GGUF, seeded synthetic" % (cfg["model"], cfg["ftype"]), "images_per_gpu": batch, "texts_per_gpu": n_texts,
-                       "text_tokens_per_gpu": int(offsets[-1]), "parallelism": "dp%d" % N},
+                       "text_tokens_per_gpu": int(offsets[-1]), "parallelism": "dp%d" % N,
+                       "last_layer": ("every row (CLIP_AMD_PRUNE_LAST=0)" if os.environ.get("CLIP_AMD_PRUNE_LAST", "1") == "0" else
+                                      "out-projection + FFN of the LAST layer computed for the pooled row of each sequence only — the rows the embeddings are taken from "
+                                      "(class token / last token, reference clip.cpp:1426-1431, 1154-1155); identical embeddings; whole_step_roofline.executed_flops_per_step")},
             "images_per_s_per_gpu": round(img_rate, 1), "texts_per_s_per_gpu": round(txt_rate, 1),
             "host_api_images_per_s": host_api,
             "host_api_images_per_s_4x_batch_per_call": host_api_x4,
