@@ -360,8 +360,9 @@ def test_resident_ffn_down_panels_do_not_change_a_bit(gpu, fixture_cache, monkey
     c1.close()
 
 
-@pytest.mark.parametrize("config,ftype,B", [("b32", "q4_0", 32), ("b32", "q4_0", 33), ("tiny14", "f16", 12), ("b32", "f16", 8)])
-def test_mid_size_batch_split_over_two_streams_is_the_two_half_batches(gpu, fixture_cache, monkeypatch, config, ftype, B):
+@pytest.mark.parametrize("config,ftype,B,rule", [("b32", "q4_0", 32, "2,64"), ("b32", "q4_0", 33, "2,64"), ("tiny14", "f16", 12, "2,64"), ("b32", "f16", 8, "2,64"),
+                                                 ("b32", "q4_0", 48, None)])        # None: the default rule (48 ViT-B/32 images = 2400 token rows: split)
+def test_mid_size_batch_split_over_two_streams_is_the_two_half_batches(gpu, fixture_cache, monkeypatch, config, ftype, B, rule):
     """Round 4: a device-resident call of 8-64 images runs as two half-batches on two streams (the context and its
     weight-sharing sibling), forked / joined with events, captured into ONE hipGraph from the second sighting on.  Bit for bit the
     embeddings of the two halves encoded separately without the split (rows are independent; determinism), on the eager first call, the
@@ -386,7 +387,10 @@ def test_mid_size_batch_split_over_two_streams_is_the_two_half_batches(gpu, fixt
     halves = np.concatenate([run(c0, imgs[:n1].contiguous())[0], run(c0, imgs[n1:].contiguous())[0]])
     whole = run(c0, imgs)[0]
     c0.close()
-    monkeypatch.setenv("CLIP_AMD_SPLIT", "2,64")     # (forced: the default rule splits by token rows, forward.cpp split_applies)
+    if rule:
+        monkeypatch.setenv("CLIP_AMD_SPLIT", rule)   # (forced: the default rule splits by token rows, forward.cpp vision_forward_launch)
+    else:
+        monkeypatch.delenv("CLIP_AMD_SPLIT", raising=False)
     c1 = gpu.Clip(p, device=0)
     same_ptr_out = torch.empty((B, proj), dtype=torch.float32, device="cuda")
     for i in range(5):                        # same pointers every time: eager, capture, replay x 3
