@@ -7,7 +7,8 @@
 // straight into the token-major residual stream and adds the position embedding; q/k/v are one GEMM
 // whose epilogue applies bias and the 1/sqrt(d_head) Q scale; attention is one fused kernel; bias +
 // GELU and bias + residual live in GEMM epilogues; LayerNorm emits the fp16 operand of the next GEMM.
-// Residual stream: f32 [rows][h] in HBM for the whole pass (as in ggml).  7 launches per layer.
+// Residual stream: f32 [rows][h] in HBM for the whole pass (as in ggml).  5 launches per layer (both LayerNorms folded into the GEMM
+// epilogues; 7 where fold_pays() keeps the LayerNorm launches); behind the last layer's attention only the pooled rows are computed.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
