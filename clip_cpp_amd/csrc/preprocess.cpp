@@ -273,7 +273,8 @@ bool preprocess_batch_device(clip_ctx * ctx, const clip_image_u8 * imgs, int n, 
     memcpy(h + o_ip, ipool.data(), ipool.size() * sizeof(int));
     memcpy(h + o_wp, wpool.data(), wpool.size() * sizeof(double));
     {
-        const int nthr = std::max(1, std::min(8, n));     // the pixel copy into pinned memory is the host cost of this path
+        static const int max_thr = [] { const char * e = getenv("CLIP_AMD_U8_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+        const int nthr = std::max(1, std::min(max_thr, n));     // the pixel copy into pinned memory is the host cost of this path
         std::vector<std::thread> pool;
         for (int t = 0; t < nthr; t++)
             pool.emplace_back([&, t]() {
