@@ -834,3 +834,90 @@ def test_reference_benchmark_program_runs_unchanged_on_the_gpu_library(gpu, fixt
         if close_calls == 0:
             assert abs(got[c][0] - a1 / 4) < 1e-4 and abs(got[c][1] - a5 / 4) < 1e-4, (c, got[c], a1, a5, report)
     assert "28 images encoded" in report and "7 texts encoded" in report, report
+
+
+def _ref_program(name):
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", name)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/%s not built (needs the reference tree)" % name)
+    return exe
+
+
+def _photo(path, seed, ny=260, nx=340, **save):
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    img = np.clip(np.stack([(np.sin(xx / 23.0) * 0.5 + 0.5) * 255, (np.cos(yy / 17.0) * 0.5 + 0.5) * 255, (3 * xx + yy) % 256], -1)
+                  + rng.normal(0, 8, (ny, nx, 3)), 0, 255).astype(np.uint8)
+    PIL.fromarray(img).save(path, **save)
+
+
+def _decoded(gpu, path):
+    import os
+    L = gpu.lib()
+    u8 = L.clip_image_u8_make()
+    assert L.clip_image_load_from_file(os.fsencode(path), u8)
+    pix = np.ctypeslib.as_array(u8.contents.data, shape=(u8.contents.ny, u8.contents.nx, 3)).copy()
+    L.clip_image_u8_free(u8)
+    return pix
+
+
+def test_reference_zero_shot_program_runs_unchanged_on_the_gpu_library(gpu, fixture_cache, tmp_path):
+    """examples/zsl.cpp compiled unchanged (oracle/_ref/ref_zsl): load, decode, clip_zero_shot_label_image, print "label = score"
+    lines in descending order.  Expected: the oracle's composition (un-normalised embeddings, cosine, softmax_with_sorting)."""
+    import re
+    import subprocess
+    exe = _ref_program("ref_zsl")
+    p = fixtures.cached_model(fixture_cache, "b32", "q4_0")
+    jpg = str(tmp_path / "z.jpg")
+    _photo(jpg, 21, quality=92)
+    labels = ["cat", "dog", "a red apple", "a photo of a car", "tree"]
+    cmd = [exe, "-m", p, "--image", jpg, "-v", "0"]
+    for l in labels:
+        cmd += ["--text", l]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = [(m.group(1), float(m.group(2))) for m in re.finditer(r"^(.+) = ([0-9.]+)$", out.stdout, re.M)]
+    assert sorted(l for l, _ in got) == sorted(labels), out.stdout
+    assert all(a[1] >= b[1] for a, b in zip(got, got[1:])), got                  # printed best first
+    orc = ref.OracleModel(p)
+    ie = orc.image_batch_encode(orc.preprocess(_decoded(gpu, jpg))[None], normalize=False)[0]
+    sims = np.array([ref.similarity(ie, orc.text_encode(orc.tokenize(l), normalize=False)) for l in labels], dtype=np.float32)
+    s0, i0 = ref.softmax_with_sorting(sims)
+    np.testing.assert_allclose([s for _, s in got], s0, atol=5e-3)
+    if np.min(np.abs(np.diff(s0))) > 1e-2:
+        assert [l for l, _ in got] == [labels[i] for i in i0]
+
+
+def test_reference_extract_program_runs_unchanged_on_the_gpu_library(gpu, fixture_cache, tmp_path):
+    """examples/extract.cpp compiled unchanged (oracle/_ref/ref_extract): one .npy per image (clip_image_encode, not normalised)
+    and per text (clip_text_encode, not normalised) in the working directory; vectors against the oracle."""
+    import subprocess
+    exe = _ref_program("ref_extract")
+    ftype = "q8_0"
+    p = fixtures.cached_model(fixture_cache, "b32", ftype)
+    files = [str(tmp_path / "a.png"), str(tmp_path / "b.jpg")]
+    _photo(files[0], 31, ny=224, nx=224)
+    _photo(files[1], 32, ny=500, nx=281, quality=85)
+    texts = ["a photo of a cat", "two dogs playing in the snow, seen from far away"]
+    cmd = [exe, "-m", p, "-v", "0"]
+    for f in files:
+        cmd += ["--image", f]
+    for t in texts:
+        cmd += ["--text", t]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    orc = ref.OracleModel(p)
+    for f in files:
+        v = np.load(str(tmp_path / ("img_vec_%s.npy" % f.rsplit("/", 1)[1])))
+        want = orc.image_batch_encode(orc.preprocess(_decoded(gpu, f))[None], normalize=False)[0]
+        assert v.shape == (1, want.size) and v.dtype == np.float32
+        assert one_minus_cos(v[0], want) < TOL_MODEL[ftype]
+        assert abs(np.linalg.norm(v[0]) / np.linalg.norm(want) - 1) < 2e-2
+    for i, t in enumerate(texts):
+        v = np.load(str(tmp_path / ("text_vec_%d.npy" % i)))
+        want = orc.text_encode(orc.tokenize(t), normalize=False)
+        assert v.shape == (1, want.size)
+        assert one_minus_cos(v[0], want) < TOL_MODEL_TEXT[ftype]
+        assert abs(np.linalg.norm(v[0]) / np.linalg.norm(want) - 1) < 2e-2

@@ -1,9 +1,11 @@
 """CPU tier: the C-ABI library loads, exports the whole clip.h / clip_amd.h surface, and its host-side
 pieces (GGUF reader, tokenizer, preprocessing, quantizer, scoring) agree with the oracle.  No GPU compute."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -210,6 +212,27 @@ def test_quantizer_bit_exact_vs_oracle_codecs(clip_lib, tmp_path, fixture_cache,
     assert not clip_lib.quantize(src, dst, 5)  # invalid itype
 
 
+def test_reference_quantize_program_runs_unchanged(clip_lib, tmp_path, fixture_cache):
+    """models/quantize.cpp compiled unchanged (oracle/_ref/ref_quantize, `make -C oracle ref`): the command-line tool a user of the
+    reference runs to produce q4_0 ... q8_0 files, here over this library's clip_model_quantize; the file it writes is the file the
+    binding's call writes, byte for byte, and bad arguments print the usage and fail."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_quantize")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_quantize not built (needs the reference tree)")
+    src = fixtures.cached_model(fixture_cache, "tiny", "f32")
+    for itype in (2, 7):
+        out = str(tmp_path / ("prog_%d.gguf" % itype))
+        r = subprocess.run([exe, src, out, str(itype)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "quantize time" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
+        same = str(tmp_path / ("call_%d.gguf" % itype))
+        assert clip_lib.quantize(src, same, itype)
+        assert open(out, "rb").read() == open(same, "rb").read()
+    r = subprocess.run([exe, src, str(tmp_path / "x.gguf"), "5"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage" in r.stderr
+    r = subprocess.run([exe, str(tmp_path / "missing.gguf"), str(tmp_path / "y.gguf"), "2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "failed to quantize" in r.stderr
+
+
 REFERENCE = "/root/reference"
 
 
@@ -227,6 +250,47 @@ def test_reference_programs_build_unchanged_against_this_library(clip_lib, tmp_p
     cmd += ["-L", libdir, "-lclip", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "prog")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the dev container")
+def test_reference_ctypes_binding_imports_and_drives_this_library(clip_lib, tmp_path, fixture_cache, monkeypatch):
+    """The reference's own Python package (examples/python_bindings/clip_cpp, SURVEY 8b "Callers") with libclip.so + the stub
+    libggml.so placed in its directory as INTEGRATION.md section 3 says: the module imports (every prototype it declares resolves),
+    its Clip class loads a GGUF and its host-side methods agree with this repo's binding.  The package is linked, not copied; the
+    encoders need a GPU and are covered by the compiled reference programs in the GPU tier."""
+    pkg = tmp_path / "clip_cpp"
+    pkg.mkdir()
+    src = os.path.join(REFERENCE, "examples", "python_bindings", "clip_cpp")
+    for f in os.listdir(src):
+        if f.endswith(".py"):
+            os.symlink(os.path.join(src, f), str(pkg / f))
+    libdir = os.path.dirname(clip_lib.LIB_PATH)
+    for so in ("libclip.so", "libggml.so"):
+        os.symlink(os.path.join(libdir, so), str(pkg / so))
+    model = fixtures.cached_model(fixture_cache, "tiny", "q4_1")
+    jpg = os.path.join(REFERENCE, "tests", "red_apple.jpg")
+    code = (
+        "import json, ctypes, clip_cpp.clip as c\n"
+        "m = c.Clip(%r, verbosity=0)\n"
+        "u8 = c.make_clip_image_u8(); ok = bool(c.clip_image_load_from_file(%r.encode(), u8)) if %r else None\n"
+        "f32 = c.make_clip_image_f32(); pre = bool(c.clip_image_preprocess(m.ctx, u8, f32)) if ok else None\n"
+        "print(json.dumps({'text': m.text_config, 'vision': m.vision_config, 'tok': m.tokenize('a photo of a red apple'),\n"
+        "                  'sim': m.calculate_similarity([1.0] + [0.0] * (m.vec_dim - 1), [0.6, 0.8] + [0.0] * (m.vec_dim - 2)),\n"
+        "                  'loaded': ok, 'pre': pre, 'nx': f32.contents.nx if pre else None}))\n") % (model, jpg, os.path.exists(jpg))
+    env = dict(os.environ, PYTHONPATH=str(tmp_path), CLIP_AMD_ALLOW_NO_DEVICE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    monkeypatch.setenv("CLIP_AMD_ALLOW_NO_DEVICE", "1")
+    mine = clip_lib.Clip(model, verbosity=0)
+    for k, v in got["text"].items():
+        assert mine.text_config[k] == pytest.approx(v)
+    for k, v in got["vision"].items():
+        assert mine.vision_config[k] == pytest.approx(v)
+    assert got["tok"] == list(mine.tokenize("a photo of a red apple"))
+    assert got["sim"] == pytest.approx(0.6, abs=1e-6)
+    if got["loaded"] is not None:
+        assert got["loaded"] and got["pre"] and got["nx"] == mine.vision_config["image_size"]
 
 
 def test_product_side_synthetic_models_load_everywhere(tmp_path, clip_lib):
