@@ -64,7 +64,9 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         if force or _newer(o, [s] + headers):
             # host files include hip_runtime.h for the runtime API only: compile them as HIP too (no kernels inside)
-            jobs.append([cc, "-x", "hip", "--offload-arch=" + ARCH] + COMMON + ["-c", s, "-o", o])
+            # -fwrapv: the file decoders run integer transforms over UNTRUSTED coefficients (a corrupt JPEG overflows the 32-bit IDCT
+            # products); wrapping is what the reference's decoder does in practice and it keeps the behaviour defined
+            jobs.append([cc, "-x", "hip", "--offload-arch=" + ARCH, "-fwrapv"] + COMMON + ["-c", s, "-o", o])
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src + ".o")

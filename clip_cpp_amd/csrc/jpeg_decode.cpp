@@ -576,7 +576,7 @@ struct Decoder {
             case 0xC2: progressive = true; if (!read_sof(len)) return false; have_sof = true; break;
             case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
                 return fail("unsupported JPEG process (lossless / arithmetic)");
-            case 0xDD: if (len != 4) return fail("bad DRI"); restart_interval = get16(); break;
+            case 0xDD: if (len != 2) return fail("bad DRI"); restart_interval = get16(); break;     // (len excludes the length field itself)
             case 0xEE:
                 if (len >= 12 && !memcmp(p, "Adobe", 5)) { saw_adobe = true; adobe_transform = p[11]; }
                 break;

@@ -88,6 +88,12 @@ bool fmt_of(int type, Fmt & f) {
     return false;
 }
 
+// float -> low byte of the truncated 32-bit integer, i.e. what `(int8_t)t` / `(uint8_t)t` compile to on x86 (cvttss2si + byte move),
+// spelled so that NaN / Inf / |t| >= 2^31 — weights of a corrupt f32 file — are defined too (the "integer indefinite" 0x80000000 -> 0)
+inline int32_t trunc_i32(float t) { return t > -2147483648.0f && t < 2147483648.0f ? (int32_t)t : INT32_MIN; }
+inline int low_i8(float t) { return (int)(int8_t)(uint8_t)(uint32_t)trunc_i32(t); }
+inline int low_u8(float t) { return (int)(uint8_t)(uint32_t)trunc_i32(t); }
+
 inline uint16_t rd16(const uint8_t * p) { uint16_t v; memcpy(&v, p, 2); return v; }
 inline void wr16(uint8_t * p, uint16_t v) { memcpy(p, &v, 2); }
 
@@ -143,7 +149,7 @@ size_t quantize_rows(int type, const float * src, void * dst, int64_t nrows, int
             const float d = amax / 127.0f;
             const float id = d ? 1.0f / d : 0.0f;
             wr16(blk, f32_to_f16_bits(d));
-            for (int j = 0; j < 32; j++) blk[f.off_qs + j] = (uint8_t)(int8_t)roundf(src[j] * id);
+            for (int j = 0; j < 32; j++) blk[f.off_qs + j] = (uint8_t)low_i8(roundf(src[j] * id));
             continue;
         }
         const int levels = 1 << f.bits;  // 16 or 32
@@ -167,10 +173,10 @@ size_t quantize_rows(int type, const float * src, void * dst, int64_t nrows, int
             int q;
             if (f.affine) {
                 const float t = (src[j] - lo) * id + 0.5f;
-                q = f.bits == 4 ? std::min(15, (int)(int8_t)t) : (int)(uint8_t)t;
+                q = f.bits == 4 ? std::min(15, low_i8(t)) : low_u8(t);
             } else {
                 const float t = src[j] * id + ((float)(levels / 2) + 0.5f);  // single add of 8.5 / 16.5
-                q = std::min(levels - 1, (int)(int8_t)t);
+                q = std::min(levels - 1, low_i8(t));
             }
             const int nib = q & 0x0F;
             blk[f.off_qs + (j & 15)] |= (uint8_t)(j < 16 ? nib : nib << 4);

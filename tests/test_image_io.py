@@ -58,7 +58,11 @@ def _photo(h, w, seed=0):
 
 JPEG_CASES = [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, progressive=True),
               dict(subsampling=0, progressive=True), dict(subsampling=1, progressive=True, quality=35), dict(quality=95, optimize=True),
-              dict(gray=True), dict(gray=True, progressive=True)]
+              dict(gray=True), dict(gray=True, progressive=True),
+              # restart intervals (DRI + RSTn markers: cameras and many encoders write them; PIL only on request)
+              dict(subsampling=2, restart_marker_blocks=1), dict(subsampling=0, restart_marker_blocks=3),
+              dict(subsampling=1, progressive=True, restart_marker_blocks=2), dict(gray=True, restart_marker_blocks=7),
+              dict(subsampling=2, restart_marker_rows=1)]
 
 
 @pytest.mark.parametrize("size", [(64, 64), (57, 83), (1, 1), (200, 3), (17, 250)])
@@ -71,6 +75,7 @@ def test_jpeg_pixels_equal_reference_decoder(clip_lib, stb, tmp_path, size, case
     buf = io.BytesIO()
     pim.save(buf, "JPEG", **{"quality": 80, **kw})
     data = buf.getvalue()
+    assert (b"\xff\xdd" in data) == any(k.startswith("restart") for k in kw)
     path = str(tmp_path / "t.jpg")
     open(path, "wb").write(data)
     want = stb(data)
