@@ -921,3 +921,35 @@ def test_reference_extract_program_runs_unchanged_on_the_gpu_library(gpu, fixtur
         assert v.shape == (1, want.size)
         assert one_minus_cos(v[0], want) < TOL_MODEL_TEXT[ftype]
         assert abs(np.linalg.norm(v[0]) / np.linalg.norm(want) - 1) < 2e-2
+
+
+@pytest.mark.parametrize("ftype", ["f16", "q4_0"])
+@pytest.mark.parametrize("config", ["tiny", "tiny14"])
+def test_every_batch_size_across_the_dispatch_boundaries_matches_the_oracle(gpu, fixture_cache, config, ftype):
+    """One small model, batches of 1 ... 300 images (17 / 5 token rows each) and 1 ... 260 ragged texts: the row counts cross every
+    boundary the dispatcher has — the <= 64-row kernels, the ring tiles, the 2000-3300-row two-stream split, the 4096-row end of the
+    mid-M rule, the LayerNorm-fold and pooled-last-layer thresholds, odd tails behind full tiles — and every embedding of every batch
+    is compared with the oracle's (computed once per image / text: the rows of a batch are independent)."""
+    path = fixtures.cached_model(fixture_cache, config, ftype)
+    clip, orc = gpu.Clip(path, device=0), ref.OracleModel(path)
+    S = clip.vision_config["image_size"]
+    T = (S // clip.vision_config["patch_size"]) ** 2 + 1
+    imgs = fixtures.synthetic_images(300, S, seed=77)
+    want = orc.image_batch_encode(imgs, normalize=True, mode=ref.MODE_FAITHFUL)
+    sizes = [1, 2, 3, 4, 5, 7, 8, 12, 13, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 117, 118, 127, 128, 129, 194, 195, 200, 240, 241, 242, 255, 256, 257, 300]
+    rows = set()
+    for i, B in enumerate(sizes):
+        lo = (i * 37) % (300 - B + 1)                                  # a different window of the 300 images each time
+        got = clip.encode_images(imgs[lo:lo + B], normalize=True)
+        d = one_minus_cos(got, want[lo:lo + B])
+        assert got.shape == (B, want.shape[1]) and np.all(d <= TOL[ftype]), (config, ftype, B, float(d.max()), int(d.argmax()))
+        rows.add(B * T)
+    assert min(rows) <= 64 < max(rows) and (T < 17 or (any(2000 <= r <= 3300 for r in rows) and max(rows) > 4096))
+    texts = fixtures.synthetic_token_ids(260, seed=9, min_len=1, max_len=75)
+    want_t = np.stack([orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL) for ids in texts])
+    for i, n in enumerate([1, 2, 3, 5, 8, 16, 31, 50, 64, 65, 100, 128, 129, 200, 260]):
+        lo = (i * 29) % (260 - n + 1)
+        got = clip.encode_texts(texts[lo:lo + n], normalize=True)
+        d = one_minus_cos(got, want_t[lo:lo + n])
+        assert np.all(d <= TOL[ftype]), (config, ftype, n, float(d.max()), int(d.argmax()))
+    clip.close()
