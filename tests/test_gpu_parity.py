@@ -953,3 +953,26 @@ def test_every_batch_size_across_the_dispatch_boundaries_matches_the_oracle(gpu,
         d = one_minus_cos(got, want_t[lo:lo + n])
         assert np.all(d <= TOL[ftype]), (config, ftype, n, float(d.max()), int(d.argmax()))
     clip.close()
+
+
+@pytest.mark.parametrize("ftype", ["q4_0", "f16"])
+def test_vit_b32_every_dispatch_boundary_gives_the_batch256_rows(gpu, fixture_cache, ftype):
+    """The same sweep at the BASELINE model's widths (tile choice depends on N and K, not only on the row count): batches of 2 ... 255
+    ViT-B/32 images (100 ... 12 750 token rows: ring tiles, the two-stream split at 2000-3300 rows, the 4096-row rule, 160 x 128 /
+    192 x 128 / panel kernels) and 1 ... 200 ragged texts, each row against the same item inside the 256-item batch (1 - cos <= 1e-6:
+    fp32 re-association between schedules only).  The anchors to the oracle are the 32-image test above and the bench's sample."""
+    p = fixtures.cached_model(fixture_cache, "b32", ftype)
+    clip = gpu.Clip(p, device=0)
+    imgs = fixtures.synthetic_images(256, 224, seed=123)
+    full = clip.encode_images(imgs)
+    for i, B in enumerate([2, 3, 5, 8, 13, 20, 21, 39, 40, 41, 47, 48, 64, 66, 67, 81, 82, 83, 100, 128, 129, 200, 255]):
+        lo = (i * 31) % (256 - B + 1)
+        d = one_minus_cos(clip.encode_images(imgs[lo:lo + B]), full[lo:lo + B])
+        assert np.all(d <= 1e-6), (ftype, B, float(d.max()), int(d.argmax()))
+    texts = fixtures.synthetic_token_ids(256, seed=41, min_len=1, max_len=75)
+    full_t = clip.encode_texts(texts)
+    for i, n in enumerate([1, 2, 3, 4, 7, 20, 50, 64, 65, 100, 128, 200]):
+        lo = (i * 23) % (256 - n + 1)
+        d = one_minus_cos(clip.encode_texts(texts[lo:lo + n]), full_t[lo:lo + n])
+        assert np.all(d <= 1e-6), (ftype, n, float(d.max()), int(d.argmax()))
+    clip.close()
