@@ -52,14 +52,16 @@ int64_t ggml_time_ms(void) { return ggml_time_us() / 1000; }
 
 // ---- model lifetime ----
 struct clip_ctx * clip_model_load(const char * fname, const int verbosity) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!fname) return nullptr;
     return load_model(fname, verbosity, default_device());
 } catch (const std::exception & e) { fprintf(stderr, "clip_model_load: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_model_load: unknown exception\n"); return nullptr; }
 struct clip_ctx * clip_amd_model_load(const char * fname, int verbosity, int device) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!fname) return nullptr;
     return load_model(fname, verbosity, device);
 } catch (const std::exception & e) { fprintf(stderr, "clip_amd_model_load: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_amd_model_load: unknown exception\n"); return nullptr; }
-void clip_free(struct clip_ctx * ctx) { free_model(ctx); }
+void clip_free(struct clip_ctx * ctx) { RelaxCapture relax_capture; free_model(ctx); }
 struct clip_text_hparams * clip_get_text_hparams(struct clip_ctx * ctx) { return &ctx->text_hparams; }
 struct clip_vision_hparams * clip_get_vision_hparams(struct clip_ctx * ctx) { return &ctx->vision_hparams; }
 
@@ -86,6 +88,7 @@ void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream) {
     ctx->stream = next;
 }
 struct clip_ctx * clip_amd_model_load_multi(const char * fname, int verbosity, int n_devices) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!fname) return nullptr;
     return multi_load(fname, verbosity, n_devices);
 } catch (const std::exception & e) { fprintf(stderr, "clip_amd_model_load_multi: %s\n", e.what()); return nullptr; } catch (...) { fprintf(stderr, "clip_amd_model_load_multi: unknown exception\n"); return nullptr; }
@@ -153,6 +156,7 @@ void clip_image_batch_preprocess(const struct clip_ctx * ctx, const int n_thread
 // ---- encoders: host-pointer forms (the reference API) ----
 bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_image_f32_batch * imgs, float * vec,
                              const bool normalize) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     (void)n_threads;
     clip_ctx * ctx = const_cast<clip_ctx *>(cctx);  // const handle, mutable workspace — as in the reference
     if (!ctx->has_vision_encoder) {
@@ -166,7 +170,6 @@ bool clip_image_batch_encode(const struct clip_ctx * cctx, const int n_threads, 
     const int B = (int)imgs->size;
     if (B <= 0) return true;
     const int S = ctx->vision_hparams.image_size, proj = ctx->vision_hparams.projection_dim;
-    const size_t per = (size_t)S * S * 3;
     for (int b = 0; b < B; b++) {
         if (imgs->data[b].nx != S || imgs->data[b].ny != S || !imgs->data[b].data) {
             fprintf(stderr, "clip_image_batch_encode: image %d is %dx%d, expected %dx%d (run clip_image_preprocess first)\n", b,
@@ -207,10 +210,12 @@ bool clip_image_encode(const struct clip_ctx * ctx, const int n_threads, struct 
 }
 
 bool clip_amd_image_batch_encode_device(struct clip_ctx * ctx, const float * d_imgs, int batch, float * d_out, bool normalize) {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     return vision_forward_device(ctx, d_imgs, batch, d_out, normalize);
 }
 
 bool clip_amd_image_batch_preprocess_device(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * d_out) {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     return preprocess_batch_device(ctx, imgs, n, d_out);
 }
 
@@ -260,6 +265,7 @@ static bool encode_u8_to_device(clip_ctx * ctx, const clip_image_u8 * imgs, int 
 }
 
 bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n, float * vec, bool normalize) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!ctx->has_vision_encoder) {
         printf("This gguf file seems to have no vision encoder\n");
         return false;
@@ -292,6 +298,7 @@ bool clip_amd_image_batch_encode_u8(struct clip_ctx * ctx, const struct clip_ima
 // Device-resident sharded image encode on a clip_amd_model_load_multi context (the measured form of SURVEY 8e: bench.py --single-process).
 // d_imgs[g]: the preprocessed f32 images of shard g ([hi - lo][S][S][3], clip_amd_shard_bounds(total, G, g)) ON device g.
 bool clip_amd_image_batch_encode_device_multi(struct clip_ctx * ctx, const float * const * d_imgs, int total, bool normalize, float * vec) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!ctx || !ctx->multi || !ctx->has_vision_encoder || !d_imgs) { fprintf(stderr, "clip_amd_image_batch_encode_device_multi: needs a clip_amd_model_load_multi context with a vision encoder\n"); return false; }
     if (total <= 0) return true;
     return multi_run(ctx, total, ctx->vision_hparams.projection_dim, vec, "clip_amd_image_batch_encode_device_multi",
@@ -301,6 +308,7 @@ bool clip_amd_image_batch_encode_device_multi(struct clip_ctx * ctx, const float
 // ... and of ragged texts: d_ids[g] = the ids of shard g's texts back to back ON device g, h_offsets = total + 1 prefix offsets of ALL texts (host).
 bool clip_amd_text_batch_encode_device_multi(struct clip_ctx * ctx, const int32_t * const * d_ids, const int32_t * h_offsets, int total, bool normalize,
                                              float * vec) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!ctx || !ctx->multi || !ctx->has_text_encoder || !d_ids || !h_offsets) { fprintf(stderr, "clip_amd_text_batch_encode_device_multi: needs a clip_amd_model_load_multi context with a text encoder\n"); return false; }
     if (total <= 0) return true;
     const int G = multi_device_count(ctx);
@@ -318,6 +326,7 @@ bool clip_amd_text_batch_encode_device_multi(struct clip_ctx * ctx, const int32_
 // device), ONE grouped all-gather carries both towers' rows.  vec_img [n_images][proj] / vec_txt [n_texts][proj] on the host, or NULL.
 bool clip_amd_encode_pair_device_multi(struct clip_ctx * ctx, const float * const * d_imgs, int n_images, const int32_t * const * d_ids,
                                        const int32_t * h_offsets, int n_texts, bool normalize, float * vec_img, float * vec_txt) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!ctx || !ctx->multi || !ctx->has_vision_encoder || !ctx->has_text_encoder || !d_imgs || !d_ids || !h_offsets) {
         fprintf(stderr, "clip_amd_encode_pair_device_multi: needs a two-tower clip_amd_model_load_multi context\n");
         return false;
@@ -359,6 +368,7 @@ static bool texts_to_device(clip_ctx * ctx, const clip_tokens * tokens, size_t n
 
 bool clip_text_batch_encode(const struct clip_ctx * cctx, const int n_threads, const struct clip_tokens * tokens, size_t n_texts, float * vec,
                             const bool normalize) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     (void)n_threads;
     clip_ctx * ctx = const_cast<clip_ctx *>(cctx);
     if (!ctx->has_text_encoder) {
@@ -400,6 +410,7 @@ bool clip_text_encode(const struct clip_ctx * ctx, const int n_threads, const st
 
 bool clip_amd_text_batch_encode_device(struct clip_ctx * ctx, const int32_t * d_ids, const int32_t * h_offsets, int n_texts, float * d_out,
                                        bool normalize) {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     return text_forward_device(ctx, d_ids, h_offsets, n_texts, d_out, normalize);
 }
 
@@ -412,6 +423,7 @@ float clip_similarity_score(const float * vec1, const float * vec2, const int ve
 
 bool clip_compare_text_and_image(const struct clip_ctx * ctx, const int n_threads, const char * text, const struct clip_image_u8 * image,
                                  float * score) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
         printf("clip_compare_text_and_image function can only be used with two-tower models\n");
         return false;
@@ -454,6 +466,7 @@ bool softmax_with_sorting(float * arr, const int length, float * sorted_scores, 
 
 bool clip_zero_shot_label_image(struct clip_ctx * ctx, const int n_threads, const struct clip_image_u8 * input_img, const char ** labels,
                                 const size_t n_labels, float * scores, int * indices) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
         printf("clip_zero_shot_label_image function can only be used with two-tower models\n");
         return false;
@@ -494,6 +507,7 @@ bool clip_amd_zero_shot_score_device(struct clip_ctx * ctx, const float * d_img,
 
 bool clip_amd_zero_shot_label_images(struct clip_ctx * ctx, const struct clip_image_u8 * imgs, int n_images, const char ** labels,
                                      size_t n_labels, float * scores, int * indices) try {
+    RelaxCapture relax_capture;     // (model.h: this thread may allocate while another thread of the process captures)
     if (!(ctx->has_text_encoder && ctx->has_vision_encoder)) {
         printf("clip_zero_shot_label_image function can only be used with two-tower models\n");
         return false;

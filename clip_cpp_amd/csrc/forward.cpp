@@ -631,6 +631,34 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
     return ok;
 }
 
+// A capture that a foreign thread invalidated (the application's own hipMalloc / hipFree on another thread: model.h RelaxCapture covers
+// this library's threads only) can leave the stream refusing every later launch on this ROCm ("operation not permitted when stream is
+// capturing" after hipStreamEndCapture has returned the invalidation).  The context and its siblings then move to fresh streams of their
+// own, behind a device synchronisation (work queued before the capture keeps its order).  False: a stream set by the caller
+// (clip_amd_set_stream) is still unusable — that one is the caller's to replace.
+bool renew_streams_after_failed_capture(clip_ctx * ctx) {
+    bool ok = true, synced = false;
+    auto one = [&](clip_ctx * c) {
+        if (!c) return;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const hipError_t qe = hipStreamIsCapturing(c->stream, &st);
+        (void)hipGetLastError();
+        if (qe == hipSuccess && st == hipStreamCaptureStatusNone) return;
+        if (c->stream != c->own_stream) { ok = false; return; }
+        if (!synced) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); synced = true; }
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+        (void)hipStreamDestroy(c->own_stream);
+        (void)hipGetLastError();
+        c->own_stream = c->stream = fresh;
+        if (c->verbosity >= 1 || (c->owner && c->owner->verbosity >= 1)) fprintf(stderr, "clip (hip): stream replaced after an invalidated capture\n");
+    };
+    one(ctx);
+    one(ctx->sibling);
+    for (clip_ctx * ms : ctx->more_siblings) one(ms);
+    return ok;
+}
+
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
     if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder)
@@ -656,6 +684,7 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
         (void)hipGetLastError();
         if (graph) (void)hipGraphDestroy(graph);
         ctx->graphs_enabled = false;   // capture not possible here: stay eager from now on
+        if (!renew_streams_after_failed_capture(ctx)) { fprintf(stderr, "clip_image_batch_encode: the caller's stream is left in an invalidated capture\n"); return false; }
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
     }
     hipGraphExec_t exec = nullptr;
@@ -980,6 +1009,8 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
             (void)hipGetLastError();
             if (graph) (void)hipGraphDestroy(graph);
             ctx->graphs_enabled = false;      // capture not possible here: stay eager from now on
+            if (!renew_streams_after_failed_capture(ctx)) { fprintf(stderr, "clip_text_encode: the caller's stream is left in an invalidated capture\n"); return false; }
+            s = ctx->stream;
         } else {
             (void)hipGetLastError();
         }

@@ -402,7 +402,7 @@ clip_ctx * multi_load(const char * fname, int verbosity, int n_devices) {
     mc->rep.assign(n_devices, nullptr);
     {
         std::vector<std::thread> loaders;
-        for (int g = 1; g < n_devices; g++) loaders.emplace_back([&, g] { mc->rep[g] = load_model(fname, 0, g % ndev); });
+        for (int g = 1; g < n_devices; g++) loaders.emplace_back([&, g] { RelaxCapture relax_capture; mc->rep[g] = load_model(fname, 0, g % ndev); });
         mc->rep[0] = load_model(fname, verbosity, 0);
         for (auto & t : loaders) t.join();
     }
@@ -489,6 +489,7 @@ bool multi_run(clip_ctx * primary, int total, int proj, float * vec, const char 
     multi_shard(total, G, 0, &lo, &hi, &per_dev);
     std::vector<char> okv(G, 1);
     auto work = [&](int g) {
+        RelaxCapture relax_capture;          // (replica threads allocate too: model.h)
         clip_ctx * c = mc->rep[g];
         (void)hipSetDevice(c->device);
         void * sp = mc->send[g], * rp = mc->recv[g];
@@ -562,6 +563,7 @@ bool multi_run_pair(clip_ctx * primary, int n_img, int n_txt, int proj, float * 
     if ((int)mc->twin.size() != G) { mc->twin.assign(G, nullptr); mc->ev_fork.assign(G, nullptr); mc->ev_join.assign(G, nullptr); }
     std::vector<char> okv(G, 1);
     auto work = [&](int g) {
+        RelaxCapture relax_capture;          // (replica threads allocate too: model.h)
         clip_ctx * c = mc->rep[g];
         (void)hipSetDevice(c->device);
         if (!mc->twin[g]) {

@@ -189,6 +189,20 @@ struct clip_ctx {
 
 namespace clipamd {
 
+// HIP checks "potentially unsafe" calls (hipMalloc, hipFree, hipMemset, stream / event creation, synchronous copies ...) against stream
+// captures in flight and, with a thread's default mode, against captures begun by OTHER threads too: the call fails and the capture is
+// invalidated (seen on ROCm 7.0 under scripts/fuzz/run_gpu.sh: one serving thread capturing a small text batch while another grew a
+// workspace).  This library captures short launch chains that contain no such call, so every entry point (and every worker thread)
+// that may allocate runs in the relaxed mode for its duration and hands the thread back as it found it.
+struct RelaxCapture {
+    hipStreamCaptureMode prev = hipStreamCaptureModeRelaxed;
+    bool armed = false;
+    RelaxCapture() { armed = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess; if (!armed) (void)hipGetLastError(); }
+    ~RelaxCapture() { if (armed) (void)hipThreadExchangeStreamCaptureMode(&prev); }
+    RelaxCapture(const RelaxCapture &) = delete;
+    RelaxCapture & operator=(const RelaxCapture &) = delete;
+};
+
 // load.cpp
 clip_ctx * load_model(const char * fname, int verbosity, int device);
 clip_ctx * sibling_context(clip_ctx * owner, int index = 0);     // owner->sibling (index 0) / more_siblings[index - 1], created on first use (nullptr on failure)
@@ -218,6 +232,7 @@ bool ensure_pinned(clip_ctx * ctx, size_t bytes);
 bool ensure_io(clip_ctx * ctx, size_t in_bytes, size_t out_bytes);
 void prof_collect(clip_ctx * ctx);
 void drop_graphs(clip_ctx * ctx);
+bool renew_streams_after_failed_capture(clip_ctx * ctx);
 
 // host_pipeline.cpp — pinned, threaded host -> device staging + the multi-GPU form of clip_image_batch_encode
 bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n, float * d_out, bool normalize, int n_threads);

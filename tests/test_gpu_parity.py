@@ -976,3 +976,68 @@ def test_vit_b32_every_dispatch_boundary_gives_the_batch256_rows(gpu, fixture_ca
         d = one_minus_cos(clip.encode_texts(texts[lo:lo + n]), full_t[lo:lo + n])
         assert np.all(d <= 1e-6), (ftype, n, float(d.max()), int(d.argmax()))
     clip.close()
+
+
+def test_graph_captures_survive_allocations_on_other_threads(gpu, fixture_cache):
+    """HIP checks hipMalloc / hipFree against stream captures in flight — also those of other threads — and invalidates the capture
+    (found with scripts/fuzz/run_gpu.sh; on ROCm 7.0 the stream then refuses every later launch).  Two cases: (a) a foreign thread of the
+    application hammers hipMalloc / hipFree while this thread's text calls capture their launch chains: every call must succeed with the
+    bits of the undisturbed call (eager relaunch on a replaced stream when a capture was lost); (b) two contexts on two threads, one
+    capturing, one growing its workspace through this library (whose entry points run in the relaxed capture mode): same requirement."""
+    import ctypes as C
+    import threading
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    clip = gpu.Clip(p, device=0)
+    texts = [[49406] + [int(v) for v in np.random.default_rng(n).integers(1, 400, n)] + [49407] for n in range(1, 41)]
+    want = [np.asarray(clip.encode_text(t), dtype=np.float32) for t in texts]           # first sighting of every shape: eager
+    hip = C.CDLL("libamdhip64.so")
+    stop = threading.Event()
+    count = [0]
+
+    def hammer():
+        hip.hipSetDevice(0)
+        ptr = C.c_void_p()
+        while not stop.is_set():
+            if hip.hipMalloc(C.byref(ptr), C.c_size_t(1 << 20)) == 0:
+                hip.hipFree(ptr)
+            count[0] += 1
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        for rep in range(3):                       # second sighting: capture (under the hammer); third: replay, or eager after a lost capture
+            for t, w in zip(texts, want):
+                assert np.array_equal(np.asarray(clip.encode_text(t), dtype=np.float32), w), (rep, len(t))
+    finally:
+        stop.set()
+        th.join()
+    assert count[0] > 100
+    # (b) this library's own threads
+    other = gpu.Clip(p, device=0)
+    S = other.vision_config["image_size"]
+    imgs = fixtures.synthetic_images(260, S, seed=5)
+    base = other.encode_images(imgs[:4])
+    texts2 = [[49406] + [int(v) for v in np.random.default_rng(100 + n).integers(1, 400, n)] + [49407] for n in range(1, 61)]
+    want2 = [np.asarray(clip.encode_text(t), dtype=np.float32) for t in texts2]
+    errs = []
+
+    def grow():
+        try:
+            for B in (8, 20, 40, 64, 100, 130, 200, 260, 4):            # growing workspaces: hipMalloc / hipFree inside the library
+                got = other.encode_images(imgs[:B])
+                if not np.all(one_minus_cos(got[:4], base) <= 1e-6):
+                    errs.append(("images", B))
+        except Exception as e:                                           # noqa: BLE001 — reported below
+            errs.append(repr(e))
+
+    th = threading.Thread(target=grow)
+    th.start()
+    try:
+        for rep in range(2):
+            for t, w in zip(texts2, want2):
+                assert np.array_equal(np.asarray(clip.encode_text(t), dtype=np.float32), w), (rep, len(t))
+    finally:
+        th.join()
+    assert not errs, errs
+    clip.close()
+    other.close()
