@@ -659,6 +659,21 @@ bool renew_streams_after_failed_capture(clip_ctx * ctx) {
     return ok;
 }
 
+namespace {
+// CLIP_AMD_TEST_BREAK_CAPTURE=1 (tests of the recovery above): an allocation in the thread-local checking mode inside the capture that has
+// just begun — what HIP forbids — so that the capture is invalidated the way a colliding thread would invalidate it
+void break_capture_for_test() {
+    static const bool on = [] { const char * e = getenv("CLIP_AMD_TEST_BREAK_CAPTURE"); return e && e[0] == '1'; }();
+    if (!on) return;
+    hipStreamCaptureMode m = hipStreamCaptureModeThreadLocal;
+    (void)hipThreadExchangeStreamCaptureMode(&m);
+    void * q = nullptr;
+    if (hipMalloc(&q, 256) == hipSuccess && q) (void)hipFree(q);
+    (void)hipThreadExchangeStreamCaptureMode(&m);
+    (void)hipGetLastError();
+}
+}  // namespace
+
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
     if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder)
@@ -677,6 +692,7 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
         (void)hipGetLastError();
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
     }
+    break_capture_for_test();
     const bool ok = vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
@@ -997,6 +1013,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
             if (ctx->tgraphs.size() >= 96) drop_graphs(ctx);
             ctx->tgraphs.push_back({n_texts, rows, nt_bucket, ids_key, d_out, normalize, 1, nullptr, nullptr});
         } else if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            break_capture_for_test();
             const bool ok = launch_all();
             hipGraph_t graph = nullptr;
             const hipError_t ce = hipStreamEndCapture(s, &graph);

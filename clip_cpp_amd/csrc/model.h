@@ -197,7 +197,12 @@ namespace clipamd {
 struct RelaxCapture {
     hipStreamCaptureMode prev = hipStreamCaptureModeRelaxed;
     bool armed = false;
-    RelaxCapture() { armed = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess; if (!armed) (void)hipGetLastError(); }
+    RelaxCapture() {
+        static const bool off = [] { const char * e = getenv("CLIP_AMD_NO_RELAX_CAPTURE"); return e && e[0] == '1'; }();    // A/B aid for tests of this guard
+        if (off) return;
+        armed = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess;
+        if (!armed) (void)hipGetLastError();
+    }
     ~RelaxCapture() { if (armed) (void)hipThreadExchangeStreamCaptureMode(&prev); }
     RelaxCapture(const RelaxCapture &) = delete;
     RelaxCapture & operator=(const RelaxCapture &) = delete;

@@ -1041,3 +1041,37 @@ def test_graph_captures_survive_allocations_on_other_threads(gpu, fixture_cache)
     assert not errs, errs
     clip.close()
     other.close()
+
+
+def test_an_invalidated_capture_falls_back_to_eager_launches_on_a_usable_stream(gpu, fixture_cache):
+    """The recovery path itself, forced: CLIP_AMD_TEST_BREAK_CAPTURE=1 makes every capture contain a forbidden allocation (the state a
+    colliding thread would leave).  The calls must still return the bits of the undisturbed context — eager relaunch, on a replaced
+    stream if HIP left the old one unusable — and keep working afterwards, for both towers."""
+    import subprocess
+    import sys
+    import os
+    p = fixtures.cached_model(fixture_cache, "tiny", "q5_1")
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import clip_cpp_amd\n"
+        "from oracle import fixtures\n"
+        "c = clip_cpp_amd.Clip(%r, device=0, verbosity=1)\n"
+        "imgs = fixtures.synthetic_images(3, c.vision_config['image_size'], seed=4)\n"
+        "ids = [49406, 5, 6, 7, 8, 49407]\n"
+        "out = []\n"
+        "for rep in range(4):\n"
+        "    out.append((c.encode_images(imgs), np.asarray(c.encode_text(ids), dtype=np.float32), c.encode_images(imgs[:1])))\n"
+        "np.savez(sys.argv[1], **{'%%s%%d' %% (k, i): o[j] for i, o in enumerate(out) for j, k in enumerate('itx')})\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), p)
+    res = {}
+    for tag, env in (("plain", {}), ("broken", {"CLIP_AMD_TEST_BREAK_CAPTURE": "1"})):
+        f = os.path.join(fixture_cache, "_break_capture_%s.npz" % tag)
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, errors="replace", timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        res[tag] = (np.load(f), r.stderr)
+    plain, broken = res["plain"][0], res["broken"][0]
+    for k in plain.files:
+        assert np.array_equal(plain[k], broken[k]), k
+        assert np.array_equal(plain[k], plain[k[0] + "0"])                 # eager (first), captured and replayed calls agree bit for bit
+    assert "stream replaced" not in res["plain"][1]
