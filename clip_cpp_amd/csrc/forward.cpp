@@ -22,17 +22,59 @@ namespace clipamd {
 
 namespace {
 
+// CLIP_AMD_GUARD=1 (debug aid; tests/test_gpu_parity.py runs the batch-size sweeps under it): 4 KB of canary bytes behind every buffer carved
+// out of an activation workspace, written before a forward and verified after it (synchronously; graphs off) — a kernel that stores past the
+// end of its buffer fails the call instead of silently touching a neighbour that the shape at hand happens not to read
+constexpr size_t kGuardBytes = 4096;
+constexpr int kGuardByte = 0xA5;
+bool guard_mode() {
+    static const bool on = [] { const char * e = getenv("CLIP_AMD_GUARD"); return e && e[0] == '1'; }();
+    return on;
+}
+
 struct Carver {
     uint8_t * base;
     size_t off = 0;
-    explicit Carver(void * b) : base((uint8_t *)b) {}
+    std::vector<size_t> * gaps = nullptr;       // guard mode: offsets of the canary blocks
+    explicit Carver(void * b, std::vector<size_t> * g = nullptr) : base((uint8_t *)b), gaps(g) { if (gaps) gaps->clear(); }
     template <typename T> T * take(size_t n) {
         off = (off + 255) & ~(size_t)255;
         T * p = base ? (T *)(base + off) : nullptr;
         off += n * sizeof(T);
+        if (guard_mode()) {
+            if (gaps) gaps->push_back(off);
+            off += kGuardBytes;
+        }
         return p;
     }
 };
+
+bool guard_arm(clip_ctx * ctx) {
+    if (!guard_mode()) return true;
+    for (size_t o : ctx->guard_gaps)
+        if (hipMemsetAsync((uint8_t *)ctx->ws.base + o, kGuardByte, kGuardBytes, ctx->stream) != hipSuccess) return false;
+    static const bool selftest = [] { const char * e = getenv("CLIP_AMD_GUARD_SELFTEST"); return e && e[0] == '1'; }();
+    if (selftest && !ctx->guard_gaps.empty())      // the checker's own test: one stray byte, 100 bytes behind the last buffer
+        return hipMemsetAsync((uint8_t *)ctx->ws.base + ctx->guard_gaps.back() + 100, 0, 1, ctx->stream) == hipSuccess;
+    return true;
+}
+
+bool guard_check(clip_ctx * ctx, const char * who) {
+    if (!guard_mode()) return true;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    std::vector<uint8_t> h(kGuardBytes);
+    bool ok = true;
+    for (size_t i = 0; i < ctx->guard_gaps.size(); i++) {
+        if (hipMemcpy(h.data(), (uint8_t *)ctx->ws.base + ctx->guard_gaps[i], kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        for (size_t k = 0; k < kGuardBytes; k++)
+            if (h[k] != (uint8_t)kGuardByte) {
+                fprintf(stderr, "%s: CLIP_AMD_GUARD: workspace buffer %zu was written %zu bytes past its end\n", who, i, k);
+                ok = false;
+                break;
+            }
+    }
+    return ok;
+}
 
 struct ProfScope {
     clip_ctx * ctx;
@@ -676,7 +718,7 @@ void break_capture_for_test() {
 
 bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * d_out, bool normalize) {
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
-    if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder)
+    if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder || guard_mode())
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);   // big batches are GPU-bound: no graph needed
     clip_ctx::GraphEntry * e = nullptr;
     for (auto & g : ctx->vgraphs)
@@ -747,9 +789,9 @@ bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st) {
     Carver sizer(nullptr);
     carve(sizer);
     if (!ensure_workspace(ctx, sizer.off + 4096)) return false;
-    Carver c(ctx->ws.base);
+    Carver c(ctx->ws.base, &ctx->guard_gaps);
     carve(c);
-    return true;
+    return guard_arm(ctx);
 }
 
 // imgs: the n images themselves (f32, or fp16 when ctx->input_f16), i0: their index inside the chunk
@@ -815,7 +857,7 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
     pj.A = st.pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = st.emb; pj.ldc = proj;
     gemm(ctx, "gemm_proj", pj, EPI_F32);   // projection, no bias (:1443)
     launch_l2norm(st.emb, d_out, Bc, proj, normalize, s);  // (:1446-1455)
-    return launch_ok("clip_image_batch_encode");
+    return launch_ok("clip_image_batch_encode") && guard_check(ctx, "clip_image_batch_encode");
 }
 
 int vision_max_chunk(const clip_ctx * ctx) {
@@ -900,8 +942,9 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     Carver sizer(nullptr);
     carve(sizer, x, xn, qkv, att, mid, pooled, emb, seq, last);
     if (!ensure_workspace(ctx, sizer.off + 4096)) return false;
-    Carver c(ctx->ws.base);
+    Carver c(ctx->ws.base, &ctx->guard_gaps);
     carve(c, x, xn, qkv, att, mid, pooled, emb, seq, last);
+    if (!guard_arm(ctx)) return false;
     {
         // sequence offsets + last-token rows (EOS, clip.cpp:1154-1155): written into a slot of a pinned ring and uploaded
         // asynchronously by a one-workgroup launch that reads the (device-mapped) slot — the host does not wait for the stream; a slot is
@@ -1003,7 +1046,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     // replay it afterwards.  The kernels read the sequence offsets from device memory (uploaded above), so a graph only depends on
     // (texts, token rows, attention key-tile bucket, pointers) — not on the individual lengths.
     const int nt_bucket = (max_len + 15) / 16;
-    if (ctx->graphs_enabled && !ctx->profiling && rows <= 1024) {
+    if (ctx->graphs_enabled && !ctx->profiling && rows <= 1024 && !guard_mode()) {
         clip_ctx::TextGraphEntry * e = nullptr;
         const void * ids_key = d_ids + h_offsets[0];
         for (auto & g : ctx->tgraphs)
@@ -1033,7 +1076,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         }
     }
     if (!launch_all()) return false;
-    return launch_ok("clip_text_encode");
+    return launch_ok("clip_text_encode") && guard_check(ctx, "clip_text_encode");
 }
 
 }  // namespace clipamd

@@ -113,6 +113,7 @@ struct clip_ctx {
     bool weights_from_cache = false;      // the HBM image came from the repacked-weight cache (CLIP_AMD_WEIGHT_CACHE), not from a repack
     clipamd::DevTower vision, text;
     clipamd::Workspace ws;           // activations, grown on demand
+    std::vector<size_t> guard_gaps;  // CLIP_AMD_GUARD=1: offsets of the canary blocks behind the buffers carved out of ws (forward.cpp)
     void * pinned = nullptr;         // pinned host staging
     size_t pinned_bytes = 0;
     void * io_in = nullptr;          // persistent device staging of the host-pointer API (stable pointers -> graph hits)

@@ -1075,3 +1075,46 @@ def test_an_invalidated_capture_falls_back_to_eager_launches_on_a_usable_stream(
         assert np.array_equal(plain[k], broken[k]), k
         assert np.array_equal(plain[k], plain[k[0] + "0"])                 # eager (first), captured and replayed calls agree bit for bit
     assert "stream replaced" not in res["plain"][1]
+
+
+def test_no_kernel_stores_past_the_end_of_its_workspace_buffer(gpu, fixture_cache):
+    """CLIP_AMD_GUARD=1: canary blocks behind every buffer of the activation workspaces, verified after every forward.  Batch sizes and text
+    lists across the dispatch boundaries on the small models, at ViT-B/32 width (q4_0, f16) and on single / few ViT-L/14 images — masked tile
+    tails, split-K seams, the pooled last layer, the two-stream split with its sibling workspace.  A violation fails the call."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import clip_cpp_amd\n"
+        "from oracle import fixtures\n"
+        "cache = %r\n"
+        "jobs = [('tiny', 'q4_0', [1, 3, 4, 17, 64, 65, 118, 194, 241, 300], [1, 2, 7, 64, 65, 260]),\n"
+        "        ('tiny14', 'f16', [1, 13, 64, 129, 300], [1, 5, 100]),\n"
+        "        ('b32', 'q4_0', [1, 2, 5, 21, 40, 48, 66, 67, 82, 129, 256], [1, 3, 20, 64, 128, 256]),\n"
+        "        ('b32', 'f16', [1, 8, 41, 83, 200], [2, 50, 200]),\n"
+        "        ('l14', 'f16', [1, 2, 9, 33], [1, 40])]\n"
+        "for cfg, ft, Bs, Ns in jobs:\n"
+        "    c = clip_cpp_amd.Clip(fixtures.cached_model(cache, cfg, ft), device=0)\n"
+        "    S = c.vision_config['image_size']\n"
+        "    imgs = fixtures.synthetic_images(max(Bs), S, seed=3)\n"
+        "    texts = fixtures.synthetic_token_ids(max(Ns), seed=4, min_len=1, max_len=75)\n"
+        "    for B in Bs:\n"
+        "        assert np.all(np.isfinite(c.encode_images(imgs[:B]))), (cfg, ft, B)\n"
+        "    for n in Ns:\n"
+        "        assert np.all(np.isfinite(c.encode_texts(texts[:n]))), (cfg, ft, n)\n"
+        "    c.close()\n"
+        "print('GUARD-OK')\n"
+    ) % (root, fixture_cache)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, errors="replace", timeout=900, env=dict(os.environ, CLIP_AMD_GUARD="1"))
+    assert r.returncode == 0 and "GUARD-OK" in r.stdout and "CLIP_AMD_GUARD" not in r.stderr, r.stdout[-1500:] + r.stderr[-3000:]
+    # the checker's own test: a stray byte planted behind the last buffer must fail the call and name the offset
+    probe = ("import sys\nsys.path.insert(0, %r)\nimport clip_cpp_amd\nfrom oracle import fixtures\n"
+             "c = clip_cpp_amd.Clip(fixtures.cached_model(%r, 'tiny', 'q4_0'), device=0)\n"
+             "try:\n    c.encode_images(fixtures.synthetic_images(2, c.vision_config['image_size'], seed=1))\n    print('NOT-CAUGHT')\n"
+             "except RuntimeError:\n    print('CAUGHT')\n") % (root, fixture_cache)
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, errors="replace", timeout=300,
+                       env=dict(os.environ, CLIP_AMD_GUARD="1", CLIP_AMD_GUARD_SELFTEST="1"))
+    assert "CAUGHT" in r.stdout and "NOT-CAUGHT" not in r.stdout and "written 100 bytes past its end" in r.stderr, r.stdout[-500:] + r.stderr[-1500:]
