@@ -51,6 +51,9 @@ struct Carver {
 
 bool guard_arm(clip_ctx * ctx) {
     if (!guard_mode()) return true;
+    // ... and the whole workspace starts as NaN bit patterns (0xFF bytes: fp16 and f32 NaN, int -1): a kernel that lets bytes nobody wrote
+    // reach an embedding (a padding column multiplied by a zero weight is enough: NaN x 0) shows up as a non-finite result
+    if (hipMemsetAsync(ctx->ws.base, 0xFF, ctx->ws.bytes, ctx->stream) != hipSuccess) return false;
     for (size_t o : ctx->guard_gaps)
         if (hipMemsetAsync((uint8_t *)ctx->ws.base + o, kGuardByte, kGuardBytes, ctx->stream) != hipSuccess) return false;
     static const bool selftest = [] { const char * e = getenv("CLIP_AMD_GUARD_SELFTEST"); return e && e[0] == '1'; }();

@@ -1101,15 +1101,22 @@ def test_no_kernel_stores_past_the_end_of_its_workspace_buffer(gpu, fixture_cach
         "    S = c.vision_config['image_size']\n"
         "    imgs = fixtures.synthetic_images(max(Bs), S, seed=3)\n"
         "    texts = fixtures.synthetic_token_ids(max(Ns), seed=4, min_len=1, max_len=75)\n"
+        "    import zlib\n"
+        "    crc = 0\n"
         "    for B in Bs:\n"
-        "        assert np.all(np.isfinite(c.encode_images(imgs[:B]))), (cfg, ft, B)\n"
+        "        e = c.encode_images(imgs[:B]); assert np.all(np.isfinite(e)), (cfg, ft, B); crc = zlib.crc32(e.tobytes(), crc)\n"
         "    for n in Ns:\n"
-        "        assert np.all(np.isfinite(c.encode_texts(texts[:n]))), (cfg, ft, n)\n"
+        "        e = c.encode_texts(texts[:n]); assert np.all(np.isfinite(e)), (cfg, ft, n); crc = zlib.crc32(e.tobytes(), crc)\n"
+        "    print('CRC', cfg, ft, crc)\n"
         "    c.close()\n"
         "print('GUARD-OK')\n"
     ) % (root, fixture_cache)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, errors="replace", timeout=900, env=dict(os.environ, CLIP_AMD_GUARD="1"))
     assert r.returncode == 0 and "GUARD-OK" in r.stdout and "CLIP_AMD_GUARD" not in r.stderr, r.stdout[-1500:] + r.stderr[-3000:]
+    # the workspace starts as NaN patterns in that mode: bytes nobody wrote must not reach an embedding — same bits as the normal run
+    plain = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, errors="replace", timeout=900, env=dict(os.environ, CLIP_AMD_GUARD="0"))
+    crcs = [l for l in r.stdout.splitlines() if l.startswith("CRC")]
+    assert plain.returncode == 0 and len(crcs) == 5 and crcs == [l for l in plain.stdout.splitlines() if l.startswith("CRC")], (crcs, plain.stdout[-800:])
     # the checker's own test: a stray byte planted behind the last buffer must fail the call and name the offset
     probe = ("import sys\nsys.path.insert(0, %r)\nimport clip_cpp_amd\nfrom oracle import fixtures\n"
              "c = clip_cpp_amd.Clip(fixtures.cached_model(%r, 'tiny', 'q4_0'), device=0)\n"
