@@ -467,9 +467,7 @@ bool pooled_tail(clip_ctx * ctx, const DevLayer & l, int n, int h, int ff, float
 const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int which, int rows) {
     if (!ctx->resident_panels_on || tw.layers.empty()) return nullptr;
     const DevLayer & l0 = tw.layers[0];
-    const DevWeight * w0[4] = {&l0.qkv, &l0.o, &l0.ff1, &l0.ff2};
     unsigned want = 0;
-    (void)w0;
     if (l0.ff2.wtype != W_F16 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
     if (!want) return nullptr;
     auto & tab = ctx->res_panels[which];
