@@ -1079,8 +1079,9 @@ def test_an_invalidated_capture_falls_back_to_eager_launches_on_a_usable_stream(
 
 def test_no_kernel_stores_past_the_end_of_its_workspace_buffer(gpu, fixture_cache):
     """CLIP_AMD_GUARD=1: canary blocks behind every buffer of the activation workspaces, verified after every forward.  Batch sizes and text
-    lists across the dispatch boundaries on the small models, at ViT-B/32 width (q4_0, f16) and on single / few ViT-L/14 images — masked tile
-    tails, split-K seams, the pooled last layer, the two-stream split with its sibling workspace.  A violation fails the call."""
+    lists across the dispatch boundaries on the small models, at ViT-B/32 width (q4_0, f16; 700 images: the 256 x 256 kernel) and on 1 ... 256 ViT-L/14
+    images (65 792 rows = 257 tile rows of that kernel) — masked tile tails, split-K seams, the pooled last layer, the two-stream split with its sibling
+    workspace.  A violation fails the call."""
     import os
     import subprocess
     import sys
@@ -1093,9 +1094,9 @@ def test_no_kernel_stores_past_the_end_of_its_workspace_buffer(gpu, fixture_cach
         "cache = %r\n"
         "jobs = [('tiny', 'q4_0', [1, 3, 4, 17, 64, 65, 118, 194, 241, 300], [1, 2, 7, 64, 65, 260]),\n"
         "        ('tiny14', 'f16', [1, 13, 64, 129, 300], [1, 5, 100]),\n"
-        "        ('b32', 'q4_0', [1, 2, 5, 21, 40, 48, 66, 67, 82, 129, 256], [1, 3, 20, 64, 128, 256]),\n"
+        "        ('b32', 'q4_0', [1, 2, 5, 21, 40, 48, 66, 67, 82, 129, 256, 700], [1, 3, 20, 64, 128, 256]),\n"
         "        ('b32', 'f16', [1, 8, 41, 83, 200], [2, 50, 200]),\n"
-        "        ('l14', 'f16', [1, 2, 9, 33], [1, 40])]\n"
+        "        ('l14', 'f16', [1, 2, 9, 33, 130, 256], [1, 40])]\n"
         "for cfg, ft, Bs, Ns in jobs:\n"
         "    c = clip_cpp_amd.Clip(fixtures.cached_model(cache, cfg, ft), device=0)\n"
         "    S = c.vision_config['image_size']\n"
