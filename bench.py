@@ -323,7 +323,7 @@ def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, s
                                    "algorithmic_bytes_per_step": by_step, "frac": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4),
                                    "note": "per GPU"},
            "roofline": None, "cpu_baseline": None,
-           "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)"}
+           "parity": "partial (the oracle's op arithmetic is unpinned against ggml — the reference ships no vectors and its ggml submodule is absent; its graph wiring, loader, tokenizer and preprocessing are bit-identical to the reference's own clip.cpp run over oracle/ggml_shim)"}
     line = json.dumps(out)
     print(line, flush=True)
     if args.json_out:
@@ -778,7 +778,7 @@ def main():
             "python_gc": "enabled" if args.python_gc else "disabled (gc.freeze + gc.disable for the run: a caller's process does not get this; --python-gc leaves it on)",
             "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
             "roofline": roofline, "whole_step_roofline": whole, "cpu_baseline": cpu_baseline, "matrix": matrix, "kernels": kernels,
-            "parity": "partial (oracle unpinned against ggml: the reference ships no vectors and its ggml submodule is absent)",
+            "parity": "partial (the oracle's op arithmetic is unpinned against ggml — the reference ships no vectors and its ggml submodule is absent; its graph wiring, loader, tokenizer and preprocessing are bit-identical to the reference's own clip.cpp run over oracle/ggml_shim)",
         }
         line = json.dumps(out)
         print(line, flush=True)

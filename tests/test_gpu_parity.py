@@ -1126,3 +1126,27 @@ def test_no_kernel_stores_past_the_end_of_its_workspace_buffer(gpu, fixture_cach
     r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, errors="replace", timeout=300,
                        env=dict(os.environ, CLIP_AMD_GUARD="1", CLIP_AMD_GUARD_SELFTEST="1"))
     assert "CAUGHT" in r.stdout and "NOT-CAUGHT" not in r.stdout and "written 100 bytes past its end" in r.stderr, r.stdout[-500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("ftype", ["f32", "f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_gpu_against_the_reference_source_itself(gpu, fixture_cache, ftype):
+    """The HIP path against /root/reference/clip.cpp ITSELF (compiled unchanged over oracle/ggml_shim: oracle/_ref/libclip_ref.so, built in the
+    dev container, travels with the snapshot; tests/test_reference_graph.py shows it equals the oracle bit for bit): a two-tower file with the
+    base model's tensor count, which the reference's loader accepts; ViT-B/32 q4_0 at full size for the q4_0 case."""
+    from oracle import ref_graph
+    if not ref_graph.available():
+        pytest.skip("oracle/_ref/libclip_ref.so not built (needs the reference tree)")
+    jobs = [("base12", 32, 5, TOL)] + ([("b32", 224, 2, TOL_MODEL)] if ftype == "q4_0" else [])
+    for cfg, S, B, tol in jobs:
+        p = fixtures.cached_model(fixture_cache, cfg, ftype)
+        R, clip = ref_graph.ReferenceModel(p), gpu.Clip(p, device=0)
+        imgs = fixtures.synthetic_images(B, S, seed=31)
+        d = one_minus_cos(clip.encode_images(imgs), R.image_batch_encode(imgs))
+        assert np.all(d <= tol[ftype]), (cfg, ftype, float(d.max()))
+        for text in ("a photo of a cat", "two dogs, a red apple & the sea!"):
+            ids = R.tokenize(text)
+            assert list(clip.tokenize(text)) == ids
+            d = one_minus_cos(np.asarray(clip.encode_text(ids), dtype=np.float32), R.text_encode(ids))
+            assert d <= (TOL_MODEL_TEXT if cfg == "b32" else tol)[ftype], (cfg, ftype, text, float(d))
+        R.close()
+        clip.close()

@@ -1,0 +1,154 @@
+"""CPU tier: the reference's OWN clip.cpp as a checker of the oracle.
+
+oracle/_ref/libclip_ref.so is /root/reference/clip.cpp compiled unchanged (`make -C oracle ref`) on top of oracle/ggml_shim — an eager
+stand-in for the slice of the un-vendored ggml submodule that clip.cpp calls, whose op arithmetic is the oracle's restatement.  What runs
+here is therefore the reference's source for: the GGUF loader (tensor names, key names, the tensor-count switch), the tokenizer
+(std::regex), the preprocessing, the scoring helpers, and the two graph builders op by op (reshape / permute / repeat / acc / get_rows
+wiring, scale-after-bias, class + position embedding, causal mask, pooling).  Bit-equality with the oracle's faithful mode pins the oracle's
+WIRING to the reference's source; the arithmetic inside the ops stays "unpinned against ggml" (oracle/ggml_shim/ggml/ggml.h).
+The library is built in the dev container only (it needs the reference tree) and travels with the snapshot."""
+import numpy as np
+import pytest
+
+from oracle import fixtures, ref, ref_graph
+
+pytestmark = pytest.mark.skipif(not ref_graph.available(), reason="oracle/_ref/libclip_ref.so not built (needs the reference tree: make -C oracle ref)")
+
+FTYPES = ["f32", "f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"]
+
+
+@pytest.mark.parametrize("ftype", FTYPES)
+def test_reference_graphs_give_the_oracles_bits(fixture_cache, ftype):
+    """Two-tower file of the base-model tensor count (397): the reference's loader takes it, both of its graphs reproduce the oracle bit for bit."""
+    p = fixtures.cached_model(fixture_cache, "base12", ftype)
+    R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
+    assert R.text_hparams()["n_layer"] == 12 and R.vision_hparams()["patch_size"] == 8
+    imgs = fixtures.synthetic_images(3, 32, seed=11)
+    for normalize in (True, False):
+        got = R.image_batch_encode(imgs, normalize=normalize)
+        want = O.image_batch_encode(imgs, normalize=normalize, mode=ref.MODE_FAITHFUL)
+        assert np.array_equal(got, want), (ftype, normalize, float(np.abs(got - want).max()))
+    assert np.array_equal(R.image_batch_encode(imgs[1:2]), O.image_batch_encode(imgs[1:2], mode=ref.MODE_FAITHFUL))
+    for ids in fixtures.synthetic_token_ids(6, seed=3, min_len=1, max_len=75) + [np.array([49406, 49407], np.int32)]:
+        for normalize in (True, False):
+            got = R.text_encode(ids, normalize=normalize)
+            want = O.text_encode(ids, normalize=normalize, mode=ref.MODE_FAITHFUL)
+            assert np.array_equal(got, want), (ftype, len(ids), normalize)
+    R.close()
+
+
+@pytest.mark.parametrize("kw,count", [(dict(text=False, vision=True), 200), (dict(text=True, vision=False), 197)])
+def test_single_tower_files_and_the_missing_tower(fixture_cache, kw, count):
+    p = fixtures.cached_model(fixture_cache, "base12", "q5_1", **kw)
+    R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
+    assert O.info["n_tensors"] == count
+    imgs = fixtures.synthetic_images(2, 32, seed=5)
+    ids = np.array([49406, 7, 8, 9, 49407], np.int32)
+    if kw["vision"]:
+        assert np.array_equal(R.image_batch_encode(imgs), O.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL))
+        assert R.text_encode(ids) is None                      # "This GGUF file seems to have no text encoder"
+    else:
+        assert np.array_equal(R.text_encode(ids), O.text_encode(ids, mode=ref.MODE_FAITHFUL))
+        assert R.image_batch_encode(imgs) is None
+    R.close()
+
+
+def test_large_model_layer_counts_and_gelu(fixture_cache):
+    """24 + 12 layers (589 tensors, the count of ViT-L/14), patch 14; and a use_gelu file (tanh-GELU table instead of quick-GELU)."""
+    p = fixtures.cached_model(fixture_cache, "large24", "q8_0")
+    R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
+    assert O.info["n_tensors"] == 589
+    imgs = fixtures.synthetic_images(2, 28, seed=6)
+    assert np.array_equal(R.image_batch_encode(imgs), O.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL))
+    ids = np.array([49406, 17, 4, 900, 49407], np.int32)
+    assert np.array_equal(R.text_encode(ids), O.text_encode(ids, mode=ref.MODE_FAITHFUL))
+    R.close()
+    p = fixtures.cached_model(fixture_cache, "base12", "f16", use_gelu=True)
+    R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(2, 32, seed=7)
+    got, want = R.image_batch_encode(imgs), O.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL)
+    assert np.array_equal(got, want)
+    quick = ref.OracleModel(fixtures.cached_model(fixture_cache, "base12", "f16")).image_batch_encode(imgs, mode=ref.MODE_FAITHFUL)
+    assert not np.array_equal(want, quick)                       # (the flag does change the network)
+    assert np.array_equal(R.text_encode(ids), O.text_encode(ids, mode=ref.MODE_FAITHFUL))
+    R.close()
+
+
+def test_vit_b32_q4_0_at_model_size(fixture_cache):
+    """BASELINE's model: the reference's graphs at ViT-B/32 q4_0 size, two images and a 42-token text, against the oracle's bits."""
+    p = fixtures.cached_model(fixture_cache, "b32", "q4_0")
+    R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(2, 224, seed=1)
+    assert np.array_equal(R.image_batch_encode(imgs), O.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL))
+    ids = np.array([49406] + list(range(100, 140)) + [49407], np.int32)
+    assert np.array_equal(R.text_encode(ids), O.text_encode(ids, mode=ref.MODE_FAITHFUL))
+    R.close()
+
+
+TEXTS = ["a photo of a cat", "", " ", "  leading  spaces ", "dog's 42!!", "isn't it're've'm'll'd", "tab\there\nnew", "x  ", "1234567 89",
+         "snowman ☃ café", "'", "''s", " 's", "!@#$%^&*()", "A B  C   D", "<|startoftext|>a<|endoftext|>", "İstanbul ǅ ß", "don’t", "a\x7fb\x01c"]
+
+
+def test_the_reference_tokenizer_itself(fixture_cache, clip_lib, monkeypatch):
+    """clip_tokenize of the reference (its std::regex, its greedy longest match) against the oracle's restatement AND the product's hand-written
+    scanner: same ids, same refusals, on the fixed cases and on 3 000 random strings."""
+    monkeypatch.setenv("CLIP_AMD_ALLOW_NO_DEVICE", "1")
+    p = fixtures.cached_model(fixture_cache, "base12", "q4_1")
+    R, O, P = ref_graph.ReferenceModel(p), ref.OracleModel(p), clip_lib.Clip(p, verbosity=0)
+
+    def product(s):
+        try:
+            return list(P.tokenize(s))
+        except RuntimeError:
+            return None
+
+    def oracle(s):
+        try:
+            return list(O.tokenize(s))
+        except Exception:      # noqa: BLE001 — the binding raises on refusal
+            return None
+
+    rng = np.random.default_rng(77)
+    pieces = list("abcdefghijklmnopqrstuvwxyzABCXYZ0123456789 \t\n\r'!?.,-_/\\\"#$%&()*+:;<=>@[]^`{|}~") + \
+        ["'s", "'t", "'re", "'ve", "'m", "'ll", "'d", "'S", "  ", " '", "é", "ß", "☃", "日本", "’", "<|startoftext|>", "<|endoftext|>", "<|", "|>", "İ"]
+    cases = list(TEXTS) + ["".join(pieces[int(i)] for i in rng.integers(0, len(pieces), int(rng.integers(0, 40)))) for _ in range(3000)]
+    for s in cases:
+        want = R.tokenize(s)
+        assert oracle(s) == want, repr(s)
+        assert product(s) == want, repr(s)
+    R.close()
+
+
+def test_the_reference_preprocessing_and_scoring(fixture_cache, clip_lib, monkeypatch):
+    """clip_image_preprocess / clip_similarity_score / softmax_with_sorting / clip_compare_text_and_image / clip_zero_shot_label_image of the
+    reference against the oracle (bit for bit) and the product's host preprocessing (bit for bit)."""
+    monkeypatch.setenv("CLIP_AMD_ALLOW_NO_DEVICE", "1")
+    p = fixtures.cached_model(fixture_cache, "base12", "f16")
+    R, O, P = ref_graph.ReferenceModel(p), ref.OracleModel(p), clip_lib.Clip(p, verbosity=0)
+    rng = np.random.default_rng(8)
+    for ny, nx in ((50, 60), (32, 32), (97, 41), (33, 200), (300, 33), (480, 640), (1, 1), (2, 500)):
+        img = rng.integers(0, 256, size=(ny, nx, 3), dtype=np.uint8)
+        want = R.preprocess(img)
+        assert np.array_equal(O.preprocess(img), want), (ny, nx)
+        assert np.array_equal(P.preprocess(img), want), (ny, nx)
+    a, b = rng.normal(size=64).astype(np.float32), rng.normal(size=64).astype(np.float32)
+    L = ref_graph.lib()
+    fp = lambda v: v.ctypes.data_as(ref_graph.C.POINTER(ref_graph.C.c_float))      # noqa: E731
+    assert L.clip_similarity_score(fp(a), fp(b), 64) == ref.similarity(a, b)
+    arr = rng.normal(size=9).astype(np.float32)
+    s_ref, i_ref = np.empty(9, np.float32), np.empty(9, np.int32)
+    assert L.softmax_with_sorting(fp(arr.copy()), 9, fp(s_ref), i_ref.ctypes.data_as(ref_graph.C.POINTER(ref_graph.C.c_int)))
+    s_orc, i_orc = ref.softmax_with_sorting(arr)
+    assert np.array_equal(s_ref, s_orc) and np.array_equal(i_ref, i_orc)
+    img = rng.integers(0, 256, size=(45, 70, 3), dtype=np.uint8)
+    text = "a photo of a red apple"
+    ie = O.image_batch_encode(O.preprocess(img)[None], normalize=True)[0]
+    te = O.text_encode(O.tokenize(text), normalize=True)
+    assert R.compare_text_and_image(text, img) == ref.similarity(ie, te)
+    labels = ["cat", "dog", "red apple", "a photo of a car", "tree"]
+    scores, idx = R.zero_shot(img, labels)
+    ie_raw = O.image_batch_encode(O.preprocess(img)[None], normalize=False)[0]
+    sims = np.array([ref.similarity(ie_raw, O.text_encode(O.tokenize(l), normalize=False)) for l in labels], dtype=np.float32)
+    s0, i0 = ref.softmax_with_sorting(sims)
+    assert np.array_equal(scores, s0) and np.array_equal(idx, i0)
+    R.close()
