@@ -151,7 +151,7 @@ void ggml_build_forward_expand(struct ggml_cgraph * cgraph, struct ggml_tensor *
 struct ggml_cplan ggml_graph_plan(struct ggml_cgraph * cgraph, int n_threads);
 int ggml_graph_compute(struct ggml_cgraph * cgraph, struct ggml_cplan * cplan);
 
-// quantisation entry points of the quantize tool (not provided by the shim: they abort with a message)
+// quantisation entry points of the quantize tool (quantize_row_*_reference over rows of k; the histogram argument is ignored)
 size_t ggml_quantize_q4_0(const float * src, void * dst, int n, int k, int64_t * hist);
 size_t ggml_quantize_q4_1(const float * src, void * dst, int n, int k, int64_t * hist);
 size_t ggml_quantize_q5_0(const float * src, void * dst, int n, int k, int64_t * hist);
@@ -185,7 +185,7 @@ const char * gguf_get_arr_str(const struct gguf_context * ctx, int key_id, int i
 int gguf_get_n_tensors(const struct gguf_context * ctx);
 size_t gguf_get_tensor_offset(const struct gguf_context * ctx, int i);
 char * gguf_get_tensor_name(const struct gguf_context * ctx, int i);
-// writer side of the quantize tool (abort with a message)
+// writer side of the quantize tool
 void gguf_set_kv(struct gguf_context * ctx, struct gguf_context * src);
 void gguf_set_val_u32(struct gguf_context * ctx, const char * key, uint32_t val);
 void gguf_add_tensor(struct gguf_context * ctx, const struct ggml_tensor * tensor);

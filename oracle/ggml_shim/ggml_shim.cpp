@@ -159,6 +159,9 @@ struct gguf_context {
     size_t alignment = 32, data_offset = 0;
     std::vector<Kv> kv;
     std::vector<TInfo> infos;
+    // writer side (gguf_init_empty): name / type / shape / byte size per tensor, offsets recomputed from the sizes
+    struct Out { std::string name; uint32_t type; uint32_t n_dims; int64_t ne[4]; size_t size; };
+    std::vector<Out> out;
 };
 
 extern "C" {
@@ -440,20 +443,80 @@ void ggml_build_forward_expand(struct ggml_cgraph * g, struct ggml_tensor * t) {
 struct ggml_cplan ggml_graph_plan(struct ggml_cgraph *, int n_threads) { ggml_cplan p; p.work_size = 0; p.work_data = nullptr; p.n_threads = n_threads; return p; }
 int ggml_graph_compute(struct ggml_cgraph *, struct ggml_cplan *) { return 0; }
 
-// ---- the quantize tool's side of the API is not provided ----
-size_t ggml_quantize_q4_0(const float *, void *, int, int, int64_t *) { die("ggml_quantize_q4_0 is not part of the shim"); }
-size_t ggml_quantize_q4_1(const float *, void *, int, int, int64_t *) { die("ggml_quantize_q4_1 is not part of the shim"); }
-size_t ggml_quantize_q5_0(const float *, void *, int, int, int64_t *) { die("ggml_quantize_q5_0 is not part of the shim"); }
-size_t ggml_quantize_q5_1(const float *, void *, int, int, int64_t *) { die("ggml_quantize_q5_1 is not part of the shim"); }
-size_t ggml_quantize_q8_0(const float *, void *, int, int, int64_t *) { die("ggml_quantize_q8_0 is not part of the shim"); }
-struct gguf_context * gguf_init_empty(void) { die("the gguf writer is not part of the shim"); }
-void gguf_set_kv(struct gguf_context *, struct gguf_context *) { die("the gguf writer is not part of the shim"); }
-void gguf_set_val_u32(struct gguf_context *, const char *, uint32_t) { die("the gguf writer is not part of the shim"); }
-void gguf_add_tensor(struct gguf_context *, const struct ggml_tensor *) { die("the gguf writer is not part of the shim"); }
-void gguf_set_tensor_type(struct gguf_context *, const char *, enum ggml_type) { die("the gguf writer is not part of the shim"); }
-void gguf_set_tensor_data(struct gguf_context *, const char *, const void *, size_t) { die("the gguf writer is not part of the shim"); }
-size_t gguf_get_meta_size(const struct gguf_context *) { die("the gguf writer is not part of the shim"); }
-void gguf_get_meta_data(const struct gguf_context *, void *) { die("the gguf writer is not part of the shim"); }
+// ---- the quantize tool's side: ggml_quantize_* = quantize_row_*_reference over rows of k (the oracle's codecs; the histogram is not kept) ----
+size_t orc_quantize(int type, const float * src, void * dst, int64_t nrows, int64_t k);
+static size_t quantize_rows_(int type, const float * src, void * dst, int n, int k) { return orc_quantize(type, src, dst, n / k, k); }
+size_t ggml_quantize_q4_0(const float * src, void * dst, int n, int k, int64_t *) { return quantize_rows_(GGML_TYPE_Q4_0, src, dst, n, k); }
+size_t ggml_quantize_q4_1(const float * src, void * dst, int n, int k, int64_t *) { return quantize_rows_(GGML_TYPE_Q4_1, src, dst, n, k); }
+size_t ggml_quantize_q5_0(const float * src, void * dst, int n, int k, int64_t *) { return quantize_rows_(GGML_TYPE_Q5_0, src, dst, n, k); }
+size_t ggml_quantize_q5_1(const float * src, void * dst, int n, int k, int64_t *) { return quantize_rows_(GGML_TYPE_Q5_1, src, dst, n, k); }
+size_t ggml_quantize_q8_0(const float * src, void * dst, int n, int k, int64_t *) { return quantize_rows_(GGML_TYPE_Q8_0, src, dst, n, k); }
+
+// ---- gguf writer: header + key/values + tensor infos, padded to the alignment (the caller writes the tensor data itself) ----
+struct gguf_context * gguf_init_empty(void) { gguf_context * g = new gguf_context(); g->version = 2; return g; }
+void gguf_set_kv(struct gguf_context * ctx, struct gguf_context * src) {
+    for (const Kv & kv : src->kv) {
+        bool found = false;
+        for (Kv & mine : ctx->kv) if (mine.key == kv.key) { mine = kv; found = true; break; }
+        if (!found) ctx->kv.push_back(kv);
+    }
+    ctx->version = src->version;
+    ctx->alignment = src->alignment;
+}
+void gguf_set_val_u32(struct gguf_context * ctx, const char * key, uint32_t val) {
+    Kv kv;
+    kv.key = key; kv.type = 4; kv.scalar = val;
+    for (Kv & mine : ctx->kv) if (mine.key == kv.key) { mine = kv; return; }
+    ctx->kv.push_back(kv);
+}
+void gguf_add_tensor(struct gguf_context * ctx, const struct ggml_tensor * t) {
+    gguf_context::Out o;
+    o.name = t->name; o.type = (uint32_t)t->type; o.n_dims = (uint32_t)t->n_dims; o.size = ggml_nbytes(t);
+    for (int i = 0; i < 4; i++) o.ne[i] = t->ne[i];
+    ctx->out.push_back(o);
+}
+static gguf_context::Out * out_by_name(struct gguf_context * ctx, const char * name) {
+    for (auto & o : ctx->out) if (o.name == name) return &o;
+    die("gguf writer: unknown tensor name");
+}
+void gguf_set_tensor_type(struct gguf_context * ctx, const char * name, enum ggml_type type) {
+    gguf_context::Out * o = out_by_name(ctx, name);
+    o->type = (uint32_t)type;
+    o->size = type_size(type) * (size_t)(o->ne[0] / blck(type)) * (size_t)(o->ne[1] * o->ne[2] * o->ne[3]);
+}
+void gguf_set_tensor_data(struct gguf_context * ctx, const char * name, const void *, size_t size) {
+    if (out_by_name(ctx, name)->size != size) die("gguf writer: data size does not match the tensor type");
+}
+static void encode_meta(const struct gguf_context * ctx, std::vector<uint8_t> & b) {
+    auto put = [&](const void * p, size_t n) { b.insert(b.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    auto pstr = [&](const std::string & v) { const uint64_t n = v.size(); put(&n, 8); put(v.data(), v.size()); };
+    put("GGUF", 4);
+    put(&ctx->version, 4);
+    const uint64_t nt = ctx->out.size(), nkv = ctx->kv.size();
+    put(&nt, 8); put(&nkv, 8);
+    for (const Kv & kv : ctx->kv) {
+        pstr(kv.key);
+        put(&kv.type, 4);
+        if (kv.type == 8) pstr(kv.str);
+        else if (kv.type == 9) {
+            put(&kv.elem_type, 4); put(&kv.n, 8);
+            if (kv.elem_type == 8) for (const std::string & e : kv.strs) pstr(e);
+            else put(kv.raw.data(), kv.raw.size());
+        } else put(&kv.scalar, scalar_size(kv.type));
+    }
+    uint64_t off = 0;
+    for (const auto & o : ctx->out) {
+        pstr(o.name);
+        put(&o.n_dims, 4);
+        for (uint32_t k = 0; k < o.n_dims; k++) { const uint64_t v = (uint64_t)o.ne[k]; put(&v, 8); }
+        put(&o.type, 4);
+        put(&off, 8);
+        off += (o.size + ctx->alignment - 1) / ctx->alignment * ctx->alignment;
+    }
+    b.resize((b.size() + ctx->alignment - 1) / ctx->alignment * ctx->alignment, 0);
+}
+size_t gguf_get_meta_size(const struct gguf_context * ctx) { std::vector<uint8_t> b; encode_meta(ctx, b); return b.size(); }
+void gguf_get_meta_data(const struct gguf_context * ctx, void * data) { std::vector<uint8_t> b; encode_meta(ctx, b); memcpy(data, b.data(), b.size()); }
 
 // ---- gguf reader (container layout: SURVEY.md Appendix A) ----
 struct gguf_context * gguf_init_from_file(const char * fname, struct gguf_init_params params) {

@@ -152,3 +152,24 @@ def test_the_reference_preprocessing_and_scoring(fixture_cache, clip_lib, monkey
     s0, i0 = ref.softmax_with_sorting(sims)
     assert np.array_equal(scores, s0) and np.array_equal(idx, i0)
     R.close()
+
+
+@pytest.mark.parametrize("src_ftype", ["f32", "f16"])
+def test_the_reference_quantize_loop_writes_the_products_file(fixture_cache, clip_lib, tmp_path, src_ftype):
+    """clip_model_quantize of the reference (its choice of tensors — 2-D names matching ".*weight" —, its f16 -> f32 conversion, its key overrides,
+    its padding; the codecs and the container writer behind it are the shim's) against the product's clip_model_quantize: the same file, byte
+    for byte, for every target type; a quantised input is refused by both."""
+    import ctypes as C
+    L = ref_graph.lib()
+    L.clip_model_quantize.restype = C.c_bool
+    L.clip_model_quantize.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    src = fixtures.cached_model(fixture_cache, "base12", src_ftype)
+    for itype in (2, 3, 6, 7, 8):
+        a, b = str(tmp_path / ("ref_%d.gguf" % itype)), str(tmp_path / ("prod_%d.gguf" % itype))
+        assert L.clip_model_quantize(src.encode(), a.encode(), itype)
+        assert clip_lib.quantize(src, b, itype)
+        assert open(a, "rb").read() == open(b, "rb").read(), (src_ftype, itype)
+    assert not L.clip_model_quantize(src.encode(), str(tmp_path / "x.gguf").encode(), 5)
+    q = fixtures.cached_model(fixture_cache, "base12", "q8_0")
+    assert not L.clip_model_quantize(q.encode(), str(tmp_path / "y.gguf").encode(), 2)
+    assert not clip_lib.quantize(q, str(tmp_path / "z.gguf"), 2)
