@@ -1150,3 +1150,22 @@ def test_gpu_against_the_reference_source_itself(gpu, fixture_cache, ftype):
             assert d <= (TOL_MODEL_TEXT if cfg == "b32" else tol)[ftype], (cfg, ftype, text, float(d))
         R.close()
         clip.close()
+
+
+def test_baseline_batch_every_row_against_the_oracle(gpu, fixture_cache):
+    """The BASELINE batch itself — 256 ViT-B/32 q4_0 images and 256 ragged texts in one call each, the shapes bench.py times — with EVERY
+    embedding compared with the oracle in ggml-faithful numerics (not a sample, not self-consistency): the oracle runs the 256 images in chunks
+    on all host cores (rows are independent)."""
+    p = fixtures.cached_model(fixture_cache, "b32", "q4_0")
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(256, 224, seed=256)
+    got = clip.encode_images(imgs)
+    want = np.concatenate([orc.image_batch_encode(imgs[i:i + 32], mode=ref.MODE_FAITHFUL) for i in range(0, 256, 32)])
+    d = one_minus_cos(got, want)
+    assert d.shape == (256,) and np.all(d <= TOL_MODEL["q4_0"]), (float(d.max()), int(d.argmax()))
+    texts = fixtures.synthetic_token_ids(256, seed=257, min_len=1, max_len=75)
+    got_t = clip.encode_texts(texts)
+    want_t = np.stack([orc.text_encode(t, mode=ref.MODE_FAITHFUL) for t in texts])
+    dt = one_minus_cos(got_t, want_t)
+    assert np.all(dt <= TOL_MODEL_TEXT["q4_0"]), (float(dt.max()), int(dt.argmax()))
+    print("batch 256: images 1-cos max %.3g mean %.3g; texts max %.3g mean %.3g" % (d.max(), d.mean(), dt.max(), dt.mean()))
