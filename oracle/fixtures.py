@@ -26,9 +26,10 @@ CONFIGS = {
     "g88": dict(v=dict(S=28, P=14, h=704, L=2, nh=8, ff=1408, proj=64), t=dict(h=64, L=2, nh=2, ff=128, proj=64, npos=77)),
     "g104": dict(v=dict(S=56, P=14, h=832, L=2, nh=8, ff=1664, proj=64), t=dict(h=64, L=2, nh=2, ff=128, proj=64, npos=77)),
     # small widths with the LAYER COUNTS of the base / large models: the reference's loader switches on the tensor count (397 / 200 / 197 for 12 + 12
-    # layers, 589 / 392 for 24 + 12; clip.cpp:261-331) and exits on any other, so these are the small files its own clip.cpp accepts (oracle/ref_graph.py)
+    # layers, 589 / 392 for 24 + 12, 909 / 520 / 389 for 32 + 24; clip.cpp:261-331) and exits on any other, so these are the small files its own clip.cpp accepts (oracle/ref_graph.py)
     "base12": dict(v=dict(S=32, P=8, h=64, L=12, nh=2, ff=128, proj=32), t=dict(h=64, L=12, nh=2, ff=128, proj=32, npos=77)),
     "large24": dict(v=dict(S=28, P=14, h=128, L=24, nh=4, ff=256, proj=64), t=dict(h=64, L=12, nh=2, ff=128, proj=64, npos=77)),
+    "huge32": dict(v=dict(S=28, P=14, h=160, L=32, nh=2, ff=320, proj=64), t=dict(h=64, L=24, nh=2, ff=128, proj=64, npos=77)),   # 909 / 520 / 389 tensors, d_head 80
     "b32": dict(v=dict(S=224, P=32, h=768, L=12, nh=12, ff=3072, proj=512), t=dict(h=512, L=12, nh=8, ff=2048, proj=512, npos=77)),
     "b16": dict(v=dict(S=224, P=16, h=768, L=12, nh=12, ff=3072, proj=512), t=dict(h=512, L=12, nh=8, ff=2048, proj=512, npos=77)),
     "l14": dict(v=dict(S=224, P=14, h=1024, L=24, nh=16, ff=4096, proj=768), t=dict(h=768, L=12, nh=12, ff=3072, proj=768, npos=77)),

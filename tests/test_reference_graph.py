@@ -63,6 +63,15 @@ def test_large_model_layer_counts_and_gelu(fixture_cache):
     ids = np.array([49406, 17, 4, 900, 49407], np.int32)
     assert np.array_equal(R.text_encode(ids), O.text_encode(ids, mode=ref.MODE_FAITHFUL))
     R.close()
+    # 32 + 24 layers (909 tensors: ViT-H/14's count, head size 80), and its text-only form (389)
+    for kw, count in ((dict(), 909), (dict(text=True, vision=False), 389)):
+        p = fixtures.cached_model(fixture_cache, "huge32", "q4_1", **kw)
+        R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
+        assert O.info["n_tensors"] == count
+        if count == 909:
+            assert np.array_equal(R.image_batch_encode(imgs), O.image_batch_encode(imgs, mode=ref.MODE_FAITHFUL))
+        assert np.array_equal(R.text_encode(ids), O.text_encode(ids, mode=ref.MODE_FAITHFUL))
+        R.close()
     p = fixtures.cached_model(fixture_cache, "base12", "f16", use_gelu=True)
     R, O = ref_graph.ReferenceModel(p), ref.OracleModel(p)
     imgs = fixtures.synthetic_images(2, 32, seed=7)
