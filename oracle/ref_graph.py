@@ -39,6 +39,10 @@ class Hparams(C.Structure):       # clip_text_hparams and clip_vision_hparams ha
 _lib = None
 
 
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
 def available():
     return os.path.exists(LIB_PATH)
 
@@ -72,12 +76,15 @@ def lib():
         L.clip_zero_shot_label_image.restype = C.c_bool
         L.clip_zero_shot_label_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(ImageU8), C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_float),
                                                  C.POINTER(C.c_int)]
+        # OpenMP team size of the op kernels = the cores this process may use (a container quota can be far below the machine's core count,
+        # and a 256-thread team spinning on 16 CPUs is pathologically slow): the oracle's own rule (ref.host_cores), set through a 1 x 1 product
+        from . import ref as _ref
+        L.orc_mul_mat.restype = C.c_int
+        L.orc_mul_mat.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float), C.c_int, C.c_int]
+        one, out = np.ones(1, np.float32), np.zeros(1, np.float32)
+        L.orc_mul_mat(0, one.ctypes.data_as(C.c_void_p), 1, 1, _fp(one), 1, _fp(out), 1, int(_ref.host_cores()))
         _lib = L
     return _lib
-
-
-def _fp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
 class ReferenceModel:

@@ -182,3 +182,52 @@ def test_the_reference_quantize_loop_writes_the_products_file(fixture_cache, cli
     q = fixtures.cached_model(fixture_cache, "base12", "q8_0")
     assert not L.clip_model_quantize(q.encode(), str(tmp_path / "y.gguf").encode(), 2)
     assert not clip_lib.quantize(q, str(tmp_path / "z.gguf"), 2)
+
+
+def test_reference_programs_on_the_reference_library(fixture_cache, tmp_path):
+    """examples/main.cpp, examples/zsl.cpp and tests/benchmark.cpp linked to libclip_ref.so (oracle/_ref/ref_*_cpu): the reference's programs on the
+    reference's own clip.cpp, end to end on the CPU — BASELINE config 1 as the reference itself would run it (ggml replaced by the shim).  Their
+    printed numbers are the oracle's composition.  (Run here only: the GPU tier compares the same programs linked to libclip.so with the oracle.)"""
+    import os
+    import re
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    ref_dir = os.path.dirname(ref_graph.LIB_PATH)
+    exes = {n: os.path.join(ref_dir, "ref_%s_cpu" % n) for n in ("main", "zsl", "benchmark")}
+    if not all(os.path.exists(e) for e in exes.values()):
+        pytest.skip("oracle/_ref/ref_*_cpu not built")
+    env = dict(os.environ, OMP_NUM_THREADS=str(ref.host_cores()))
+    p = fixtures.cached_model(fixture_cache, "base12", "f16")
+    O = ref.OracleModel(p)
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:120, 0:160]
+    img = np.clip(np.stack([(np.sin(xx / 9.0) * 0.5 + 0.5) * 255, (np.cos(yy / 7.0) * 0.5 + 0.5) * 255, (xx + 2 * yy) % 256], -1) + rng.normal(0, 6, (120, 160, 3)), 0, 255).astype(np.uint8)
+    png = str(tmp_path / "p.png")
+    PIL.fromarray(img).save(png)
+    text = "a photo of a red apple"
+    out = subprocess.run([exes["main"], "-m", p, "--image", png, "--text", text, "-v", "0"], capture_output=True, text=True, timeout=300, env=env)
+    m = re.search(r"Similarity score = ([-0-9.]+)", out.stdout)
+    assert out.returncode == 0 and m, out.stdout[-800:] + out.stderr[-800:]
+    ie = O.image_batch_encode(O.preprocess(img)[None], normalize=True)[0]
+    assert abs(float(m.group(1)) - ref.similarity(ie, O.text_encode(O.tokenize(text), normalize=True))) <= 5.1e-4        # three decimals printed
+    labels = ["cat", "dog", "a red apple", "tree"]
+    cmd = [exes["zsl"], "-m", p, "--image", png, "-v", "0"]
+    for l in labels:
+        cmd += ["--text", l]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    got = [(g.group(1), float(g.group(2))) for g in re.finditer(r"^(.+) = ([0-9.]+)$", out.stdout, re.M)]
+    assert out.returncode == 0 and len(got) == 4, out.stdout[-800:] + out.stderr[-800:]
+    ie_raw = O.image_batch_encode(O.preprocess(img)[None], normalize=False)[0]
+    sims = np.array([ref.similarity(ie_raw, O.text_encode(O.tokenize(l), normalize=False)) for l in labels], dtype=np.float32)
+    s0, i0 = ref.softmax_with_sorting(sims)
+    np.testing.assert_allclose([v for _, v in got], s0, atol=5.1e-5)                        # four decimals printed
+    root = tmp_path / "tree"
+    for ci, c in enumerate(("cat", "dog")):
+        (root / c).mkdir(parents=True)
+        for k in range(4):                                 # (the program encodes whole batches of 4 per class directory)
+            PIL.fromarray(np.roll(img, 17 * (4 * ci + k), axis=1)).save(str(root / c / ("i%d.png" % k)))
+    rep = str(tmp_path / "report.txt")
+    out = subprocess.run([exes["benchmark"], p, str(root), "0", rep], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-800:] + out.stderr[-800:]
+    report = open(rep).read()
+    assert "8 images encoded" in report and "2 texts encoded" in report, report
