@@ -9,7 +9,7 @@ ARCH    ?= gfx950
 hooks   ?= 1
 SRC     := clip_cpp_amd/csrc
 OUT     := clip_cpp_amd/build
-CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result -Wno-inline-asm -Iinclude --offload-arch=$(ARCH) -DCLIPAMD_TEST_HOOKS=$(hooks)
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result -Wno-inline-asm -Wno-bitwise-instead-of-logical -Iinclude --offload-arch=$(ARCH) -DCLIPAMD_TEST_HOOKS=$(hooks)
 HOST    := gguf quant load forward tokenizer preprocess image_io jpeg_decode host_pipeline api
 KERNELS := k_attn k_misc k_preproc k_gemm k_gemm8 k_gemm4 k_skinny k_gemm_ring k_fold
 WTS     := 0 1 2 3 4 5
@@ -19,8 +19,9 @@ all: clip_cpp_amd/libclip.so clip_cpp_amd/libggml.so
 
 $(OUT):
 	mkdir -p $(OUT)
+# (-fwrapv: the file decoders run integer transforms over untrusted coefficients; same flag as clip_cpp_amd/build.py)
 $(OUT)/%.cpp.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) include/clip.h include/clip_amd.h | $(OUT)
-	$(HIPCC) -x hip $(CXXFLAGS) -c $< -o $@
+	$(HIPCC) -x hip -fwrapv $(CXXFLAGS) -c $< -o $@
 $(OUT)/%.hip.o: $(SRC)/%.hip $(wildcard $(SRC)/*.h) | $(OUT)
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 $(OUT)/k_gemm_wt%.o: $(SRC)/k_gemm.hip $(wildcard $(SRC)/*.h) | $(OUT)
