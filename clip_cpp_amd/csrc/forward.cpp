@@ -466,6 +466,12 @@ bool pooled_tail(clip_ctx * ctx, const DevLayer & l, int n, int h, int ff, float
 // Table entry 4 * layer + {0 q/k/v, 1 out, 2 FFN-up, 3 FFN-down}; null = multiply the quantised planes.  Built outside graph captures.
 const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int which, int rows) {
     if (!ctx->resident_panels_on || tw.layers.empty()) return nullptr;
+    if (ctx->owner) {
+        // a sibling / twin multiplies the owner's weight image and borrows the owner's panels too (read-only, same device) instead of
+        // building a second 57 MB copy; it never builds: until the owner has, it runs the fused kernels (same bits — tested)
+        clip_ctx * o = ctx->owner;
+        return (o->res_panel_mask[which] && o->res_panels[which].size() == 4 * tw.layers.size()) ? o->res_panels[which].data() : nullptr;
+    }
     const DevLayer & l0 = tw.layers[0];
     unsigned want = 0;
     if (l0.ff2.wtype != W_F16 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
@@ -498,6 +504,7 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
             off += (size_t)ws[i]->Npad * ws[i]->Kpad;
         }
     }
+    (void)hipStreamSynchronize(ctx->stream);                   // one-time build: siblings read the table on their own streams (borrowed above)
     ctx->res_panel_mask[which] = want;
     return tab.data();
 }
@@ -652,6 +659,7 @@ static bool vision_forward_launch(clip_ctx * ctx, const float * d_imgs, int B, f
             if (!part_ctx[w]) { ways = 1; break; }
         }
     }
+    ctx->last_launch_split = ways >= 2;
     if (ways < 2) return vision_forward_one(ctx, d_imgs, B, d_out, normalize);
     const size_t per = (size_t)ctx->vision_hparams.image_size * ctx->vision_hparams.image_size * 3;
     const int proj = ctx->vision_hparams.projection_dim;
@@ -721,13 +729,28 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
     if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder || guard_mode())
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);   // big batches are GPU-bound: no graph needed
-    clip_ctx::GraphEntry * e = nullptr;
-    for (auto & g : ctx->vgraphs)
-        if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize && g.in_f16 == ctx->input_f16) { e = &g; break; }
-    if (e && e->exec) return hipGraphLaunch(e->exec, ctx->stream) == hipSuccess;
+    // (looked up again after every vision_forward_launch: growing a sibling's workspace drops this context's graphs — ensure_workspace)
+    auto find = [&]() -> clip_ctx::GraphEntry * {
+        for (auto & g : ctx->vgraphs)
+            if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize && g.in_f16 == ctx->input_f16) return &g;
+        return nullptr;
+    };
+    clip_ctx::GraphEntry * e = find();
+    if (e && e->exec) {
+        // a graph captured with the batch split over the sibling context holds kernel nodes that write the sibling's workspace: while the
+        // sibling carries the text tower of a pair call (host_pipeline.cpp) it must not be replayed — the eager path honours sibling_busy
+        if (e->split && ctx->sibling_busy) return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+        return hipGraphLaunch(e->exec, ctx->stream) == hipSuccess;
+    }
     if (!e) {   // first sighting: run eagerly (allocates the workspace, sets kernel attributes)
         if (ctx->vgraphs.size() >= 16) drop_graphs(ctx);
-        ctx->vgraphs.push_back({B, d_imgs, d_out, normalize, ctx->input_f16, 1, nullptr, nullptr});
+        ctx->vgraphs.push_back({B, d_imgs, d_out, normalize, ctx->input_f16, 1, nullptr, nullptr, false, ctx->sibling_busy});
+        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    }
+    if (e->busy_seen != ctx->sibling_busy) {
+        // the eager sighting took the other split decision (the sibling was busy then and is free now, or the reverse): once more eagerly, so
+        // that the form about to be captured has run — and sized every workspace it touches — outside a capture
+        e->busy_seen = ctx->sibling_busy;
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
     }
     // second sighting: capture
@@ -737,9 +760,11 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
     }
     break_capture_for_test();
     const bool ok = vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
+    const bool captured_split = ctx->last_launch_split;
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-    if (!ok || ce != hipSuccess || !graph) {
+    e = find();              // (the vector may have been cleared under the launch: never keep the pointer across it)
+    if (!ok || ce != hipSuccess || !graph || !e) {
         (void)hipGetLastError();
         if (graph) (void)hipGraphDestroy(graph);
         ctx->graphs_enabled = false;   // capture not possible here: stay eager from now on
@@ -755,6 +780,7 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
     }
     e->graph = graph;
     e->exec = exec;
+    e->split = captured_split;
     return hipGraphLaunch(exec, ctx->stream) == hipSuccess;
 }
 

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <algorithm>
 #include <memory>
+#include <ctime>
+#include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -276,6 +278,20 @@ struct WeightCache {
         }
         return i < n ? fnv(h, b + i, n - i) : h;
     }
+    // a writer that died between mkstemp and rename leaves "<image>.tmp.XXXXXX" behind for good: temporaries of THIS image older than
+    // ten minutes (no live writer takes that long) are unlinked when the cache is opened
+    static void sweep_stale_temporaries(const char * dir, const std::string & prefix) {
+        DIR * d = opendir(dir);
+        if (!d) return;
+        const time_t now = time(nullptr);
+        while (const dirent * e = readdir(d)) {
+            if (strncmp(e->d_name, prefix.c_str(), prefix.size()) != 0) continue;
+            const std::string p = std::string(dir) + "/" + e->d_name;
+            struct stat st;
+            if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode) && now - st.st_mtime > 600) (void)remove(p.c_str());
+        }
+        closedir(d);
+    }
     void init(const GgufFile & g, const char * fname) {
         const char * dir = getenv("CLIP_AMD_WEIGHT_CACHE");
         if (!dir || !dir[0] || !g.file_base()) return;
@@ -310,6 +326,7 @@ struct WeightCache {
         snprintf(hex, sizeof hex, "%016llx", (unsigned long long)key);
         path = std::string(dir) + "/" + (base ? base + 1 : fname) + "." + hex + ".hbm";
         enabled = true;
+        sweep_stale_temporaries(dir, std::string(base ? base + 1 : fname) + "." + hex + ".hbm.tmp.");
         FILE * f = fopen(path.c_str(), "rb");
         if (!f) return;
         Header hd;
@@ -338,6 +355,9 @@ struct WeightCache {
         std::string tmp = path + ".tmp.XXXXXX";
         const int fd = mkstemp(&tmp[0]);
         if (fd < 0) return;
+        // mkstemp creates the file 0600; the published image keeps that mode through the rename, and a cache directory shared between
+        // users / services would silently stop being shared (everyone else repacks on every load).  Give it what fopen would have: 0666 & ~umask.
+        { const mode_t um = umask(0); (void)umask(um); (void)fchmod(fd, 0666 & ~um); }
         FILE * f = fdopen(fd, "wb");
         if (!f) { (void)close(fd); (void)remove(tmp.c_str()); return; }
         Header hd;
@@ -620,6 +640,7 @@ clip_ctx * sibling_context(clip_ctx * owner, int index) {
     c->weights_borrowed = true;
     c->owner = owner;
     c->ln_fold = owner->ln_fold; c->ln_fold_force = owner->ln_fold_force; c->ln_fold_centre = owner->ln_fold_centre; c->prune_last = owner->prune_last;
+    c->resident_panels_on = owner->resident_panels_on;           // (the table itself is the OWNER's: forward.cpp resident_panels — read-only, same device)
     c->graphs_enabled = false;                                   // (its launches are captured into the OWNER's graphs)
     c->split_min = c->split_max = 0;                             // (a sibling never splits)
     c->verbosity = 0; c->path = owner->path;

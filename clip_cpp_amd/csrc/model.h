@@ -134,6 +134,7 @@ struct clip_ctx {
     int split_ways = 2;
     bool weights_borrowed = false;   // this IS a sibling: weights_base belongs to the owner
     clip_ctx * owner = nullptr;      // (sibling only) the context whose captured graphs hold pointers into this one's workspace
+    bool last_launch_split = false;  // vision_forward_launch: the last call ran as parts on this context and its sibling(s)
     bool sibling_busy = false;       // the sibling is carrying something else right now (the text tower of a two-tower multi call): no batch split
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int split_min = -1, split_max = -1;    // images per call for which the forward is split over two contexts; -1 = the measured default rule by token rows (forward.cpp); CLIP_AMD_SPLIT=min,max[,ways] overrides, 0,0 = off
@@ -176,7 +177,10 @@ struct clip_ctx {
 
     // hipGraph cache for the vision forward (launch-bound at small batch: ~90 launches per pass).  A pass is captured the
     // second time the same (batch, input pointer, output pointer, normalize) signature is seen and replayed afterwards.
-    struct GraphEntry { int B; const void * in; void * out; bool norm; bool in_f16; int seen; hipGraph_t graph; hipGraphExec_t exec; };
+    // split: the capture holds kernel nodes on the sibling context (batch split over two streams) — such a graph must not be replayed
+    // while the sibling carries something else (sibling_busy); busy_seen: sibling_busy at the last eager sighting — a capture happens
+    // only behind an eager run that took the same split decision, so every workspace the captured form needs already has its size
+    struct GraphEntry { int B; const void * in; void * out; bool norm; bool in_f16; int seen; hipGraph_t graph; hipGraphExec_t exec; bool split; bool busy_seen; };
     std::vector<GraphEntry> vgraphs;
     // ... and for the text forward at small token counts (single texts, short label lists): keyed on (texts, token rows,
     // attention key-tile bucket, pointers); the per-call sequence offsets live in device memory and are uploaded before the replay

@@ -516,6 +516,50 @@ def test_vit_l14_batch130_largest_m_kernels_match_single_images(gpu, fixture_cac
         np.testing.assert_allclose(one[0], full[i], atol=3e-4)
 
 
+@pytest.mark.parametrize("config,ftype,B,rows,expect", [
+    # BASELINE config 3: ViT-L/14 f16, 256 images = 65792 token rows in ONE call: 256 x 256 four-wave GEMMs (k_gemm4.hip) on the whole rounds + a
+    # second launch for the rows past them (image 255 straddles that seam), LayerNorm launches (fold_pays() declines), attn_kernel<17, ...>
+    ("l14", "f16", 256, [0, 1, 63, 127, 128, 200, 254, 255], ["gemm4_kernel<", "layernorm", "attention"]),
+    # config 4, one GPU's shard: ViT-L/14 q5_1, 128 images = 32896 rows: the same kernels on per-layer fp16 panels (dequant_layer)
+    ("l14", "q5_1", 128, [0, 1, 31, 63, 64, 100, 126, 127], ["gemm4_kernel<", "dequant_layer", "layernorm"]),
+    # config 5, one batch of the zero-shot harness: ViT-H/14 q8_0 (d_head 80, 32 layers), 64 images = 16448 rows: fused-dequant q8_0 tiles
+    ("h14", "q8_0", 64, [0, 1, 15, 31, 32, 47, 62, 63], ["gemm_dma_kernel<5,", "attention"]),
+])
+def test_baseline_configs_3_4_5_at_their_benchmarked_batch_against_the_oracle(gpu, fixture_cache, config, ftype, B, rows, expect):
+    """the kernels BASELINE configs 3-5 are TIMED on, checked against the oracle (reference path clip.cpp:1247-1523) and
+    not only by batch invariance: the whole benchmarked batch goes through the device-pointer entry bench.py times in ONE call, and eight
+    embeddings spread over it — first, last, the images either side of the middle, the one that straddles the whole-rounds seam of the
+    256 x 256 kernel — are compared with the oracle in ggml-faithful numerics at TOL_MODEL.  A profiled repeat of the same call names the
+    kernels that ran, so the test fails if the dispatch ever moves these shapes off the kernels it is meant to cover."""
+    torch = pytest.importorskip("torch")
+    p = fixtures.cached_model(fixture_cache, config, ftype, text=False, vision=True)
+    clip, orc = gpu.Clip(p, device=0), ref.OracleModel(p)
+    proj = clip.vision_config["projection_dim"]
+    imgs = fixtures.synthetic_images(B, 224, seed=300 + B)
+    d_in = torch.from_numpy(imgs).cuda()
+    d_out = torch.full((B, proj), float("nan"), dtype=torch.float32, device="cuda")
+    clip.encode_images_device(d_in.data_ptr(), B, d_out.data_ptr(), True)
+    clip.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    want = orc.image_batch_encode(imgs[rows], mode=ref.MODE_FAITHFUL)
+    d = one_minus_cos(got[rows], want)
+    assert np.all(d <= TOL_MODEL[ftype]), (config, ftype, B, d.tolist())
+    # the kernels behind that call (HIP-event profiling of a repeat; same dispatch — profiling only disables graphs and the mid-batch split)
+    clip.profile(True)
+    d_out.fill_(float("nan"))
+    clip.encode_images_device(d_in.data_ptr(), B, d_out.data_ptr(), True)
+    clip.synchronize()
+    tags = list(clip.profile_report().keys())
+    clip.profile(False)
+    assert np.array_equal(d_out.cpu().numpy(), got)
+    for e in expect:
+        assert any(e in t for t in tags), (e, tags)
+    print("%s %s batch %d: 1-cos vs oracle over rows %s: max %.3g mean %.3g" % (config, ftype, B, rows, d.max(), d.mean()))
+    clip.close()
+
+
 def test_batches_beyond_one_workspace_chunk_and_stream_restore(gpu, fixture_cache):
     """More images than one forward chunk (1024) and than one host-API staging chunk (256): rows must equal the small-batch
     results bit for bit (tiny model: no split-K at any size; batches of > 64 token rows: the LayerNorm statistics do not depend on
@@ -695,8 +739,19 @@ def test_load_from_repacked_weight_cache_encodes_bit_identically(gpu, fixture_ca
         first = gpu.Clip(p, device=0)
         assert not first.weights_from_cache
         first.close()
+        # the published image carries the mode fopen would have given it (a shared cache directory stays shared; mkstemp's 0600
+        # would not), and a temporary left behind by a writer that died before its rename is swept when the cache is opened again
+        hbm = [f for f in os.listdir(tmp_path) if f.endswith(".hbm") and os.path.basename(p) in f]
+        assert len(hbm) == 1, os.listdir(tmp_path)
+        um = os.umask(0); os.umask(um)
+        assert (os.stat(tmp_path / hbm[0]).st_mode & 0o777) == (0o666 & ~um)
+        stale, fresh = tmp_path / (hbm[0] + ".tmp.dEaDbF"), tmp_path / (hbm[0] + ".tmp.aLiVe0")
+        stale.write_bytes(b"x" * 64); fresh.write_bytes(b"y" * 64)
+        os.utime(stale, (1.0e9, 1.0e9))
         cached = gpu.Clip(p, device=0)
         assert cached.weights_from_cache
+        assert not stale.exists() and fresh.exists()
+        fresh.unlink()
         assert np.array_equal(cached.encode_images(imgs), want_i) and np.array_equal(cached.encode_texts(toks), want_t)
         cached.close()
 

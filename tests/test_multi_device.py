@@ -119,6 +119,56 @@ def test_pair_call_through_rccl_on_one_device(clip_lib, fixture_cache, monkeypat
 
 
 @pytest.mark.gpu
+def test_split_graph_is_not_replayed_while_the_sibling_carries_the_text_tower(clip_lib, fixture_cache, monkeypatch):
+    """a vision hipGraph captured with the batch split over the sibling context holds kernel nodes that write the
+    sibling's workspace.  clip_amd_encode_pair_device_multi runs the TEXT tower on that sibling; when it hits the same (batch, in, out)
+    key — the replica's send buffer is stable — the graph must not be replayed (the eager path runs unsplit while sibling_busy).
+    Sequence pair, images, images (capture, split), images (replay), then pairs: every result bit-identical to single-context calls."""
+    if clip_lib.device_count() < 1:
+        pytest.fail("GPU tier needs a HIP device")
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("CLIP_AMD_MULTI_FORCE_RCCL", "1")
+    p = fixtures.cached_model(fixture_cache, "tiny14", "f16", text=True, vision=True)
+    S, proj = fixtures.CONFIGS["tiny14"]["v"]["S"], fixtures.CONFIGS["tiny14"]["v"]["proj"]
+    B, NT = 12, 200
+    imgs = fixtures.synthetic_images(B, S, seed=77)
+    texts = fixtures.synthetic_token_ids(NT, seed=78, min_len=20, max_len=60)
+    monkeypatch.setenv("CLIP_AMD_SPLIT", "0,0")
+    single = clip_lib.Clip(p, device=0)
+    n1 = (B + 1) // 2
+    halves = np.concatenate([single.encode_images(imgs[:n1]), single.encode_images(imgs[n1:])])     # what a split call gives, bit for bit
+    whole = single.encode_images(imgs)
+    want_t = single.encode_texts(texts)
+    single.close()
+    monkeypatch.setenv("CLIP_AMD_SPLIT", "2,64")
+    multi = clip_lib.Clip(p, n_devices=1)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_ids = torch.from_numpy(np.concatenate(texts).astype(np.int32)).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(t) for t in texts])]).astype(np.int32)
+    torch.cuda.synchronize()
+
+    def pair():
+        oi, ot = np.zeros((B, proj), np.float32), np.zeros((NT, proj), np.float32)
+        multi.encode_pair_device_multi([d_img.data_ptr()], B, [d_ids.data_ptr()], offs, True, oi, ot)
+        return oi, ot
+
+    def images():
+        return multi.encode_images_device_multi([d_img.data_ptr()], B, True, np.zeros((B, proj), np.float32))
+
+    oi, ot = pair()                                        # first sighting of the key, sibling busy: eager, unsplit
+    assert np.array_equal(oi, whole) and np.array_equal(ot, want_t)
+    for i in range(4):                                     # eager split, capture (split), replays
+        assert np.array_equal(images(), halves), i
+    for i in range(6):                                     # the captured split graph must stay out of the sibling's way
+        oi, ot = pair()
+        assert np.array_equal(oi, whole), ("pair images", i)
+        assert np.array_equal(ot, want_t), ("pair texts", i)
+        assert np.array_equal(images(), halves), ("images after pair", i)
+    multi.close()
+    monkeypatch.delenv("CLIP_AMD_SPLIT", raising=False)
+
+
+@pytest.mark.gpu
 def test_rccl_all_gather_path_with_two_devices(clip_lib, fixture_cache):
     if clip_lib.device_count() < 2:
         pytest.skip("needs >= 2 visible HIP devices (the 1-GPU box runs the over-subscribed form above)")
