@@ -96,6 +96,7 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
     }
     // ---- mask + softmax.  lane holds query fq, keys kt*16 + fg*4 + r ----
     float inv[QB];
+    h8 pk[QB][NPR];
 #pragma unroll
     for (int j = 0; j < QB; j++) {
         const int kmax = t.causal ? (qrow[j] < len - 1 ? qrow[j] : len - 1) : len - 1;   // last visible key
@@ -118,19 +119,34 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
         // exp(s - mx) = exp2(s*log2(e) - mx*log2(e)): one fma + the hardware exp2 per score
         const float L2E = 1.44269504088896340736f;
         const float nmx = -mx * L2E;                     // key 0 is always visible -> mx is finite
+        // the exp'd scores are packed to fp16 — the MFMA A operand of P V: keys of two adjacent 16-key tiles form one K = 32 slice — as
+        // they are produced, so the f32 score registers die here instead of living through the second contraction (NT = 17 / 18 with
+        // query-block pairs: 136 score registers + 32 output accumulators + fragments did not fit 256 and spilled)
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NT; kt++) {
+        for (int pr = 0; pr < NPR; pr++) {
+            float e[8];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kt][r], L2E, nmx));
-                s[j][kt][r] = e;
-                sum += e;
+                e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][2 * pr][r], L2E, nmx));
+                e[4 + r] = (2 * pr + 1 < NT) ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][(2 * pr + 1 < NT) ? 2 * pr + 1 : 0][r], L2E, nmx)) : 0.f;
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) sum += e[r];
+            if (2 * pr + 1 < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) sum += e[4 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) pk[j][pr][r] = (_Float16)e[r];
+            // (bounded like the fragment prefetch above: hoisted, all 68 scaled differences of a block are computed before the first exp2)
+            if (QB > 1 && NT >= 17 && (pr & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         inv[j] = 1.0f / sum;
+        // one query block's softmax at a time: interleaved (hipcc's choice), both blocks' f32 scores AND both packed copies were live at once
+        if (QB > 1) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- O = P V : pairs of key tiles form one K=32 slice; one V^T fragment read feeds QB MFMAs ----
     f4 o[QB][DT];
@@ -140,15 +156,6 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
         for (int dt = 0; dt < DT; dt++) o[j][dt] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pr = 0; pr < NPR; pr++) {
-        h8 pf[QB];
-#pragma unroll
-        for (int j = 0; j < QB; j++) {
-            const f4 p0 = s[j][2 * pr];
-            f4 p1 = (f4){0.f, 0.f, 0.f, 0.f};
-            if (2 * pr + 1 < NT) p1 = s[j][(2 * pr + 1 < NT) ? 2 * pr + 1 : 0];
-            pf[j][0] = (_Float16)p0[0]; pf[j][1] = (_Float16)p0[1]; pf[j][2] = (_Float16)p0[2]; pf[j][3] = (_Float16)p0[3];
-            pf[j][4] = (_Float16)p1[0]; pf[j][5] = (_Float16)p1[1]; pf[j][6] = (_Float16)p1[2]; pf[j][7] = (_Float16)p1[3];
-        }
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) {
             const half_t * vrow = t.Vt + (dt * 16 + fq) * VSTRIDE + pr * 32 + fg * 4;
@@ -158,7 +165,7 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
             vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
             vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
 #pragma unroll
-            for (int j = 0; j < QB; j++) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[j], vf, o[j][dt], 0, 0, 0);
+            for (int j = 0; j < QB; j++) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pk[j][pr], vf, o[j][dt], 0, 0, 0);
         }
         if ((pr & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
     half_t * Ks = (half_t *)smem_raw;                // [NT*16][KSTRIDE]
     half_t * Vt = Ks + NT * 16 * KSTRIDE;            // [DH][VSTRIDE]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: an SGPR)
     const int seq = blockIdx.x / p.n_head, head = blockIdx.x % p.n_head;
     int row0, len;
     if (p.seq_start) {
@@ -290,7 +297,16 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
         for (int u = slot; u < npair; u += nslot) attn_blocks<NT, DKS, DT, 2, DHR>(t, 2 * u);
         // the odd last block: its wave rotates with the workgroup index — T = 257 is 8 pairs + 1 block, and with the extra block always on
         // wave npair % 4 the SIMD that hosts that wave of BOTH co-resident workgroups carries 10 blocks against 8 on the other three
-        if ((nqb & 1) && slot == (npair + (int)blockIdx.x) % nslot) attn_blocks<NT, DKS, DT, 1, DHR>(t, nqb - 1);
+        if ((nqb & 1) && slot == (npair + (int)blockIdx.x) % nslot) {
+            // the lane coordinates are derived again (v_mbcnt, opaque to CSE) instead of being kept across the pair loop: at NT = 17 / 18 that
+            // loop uses all 256 registers and the two values it had to keep for this call were spilled to scratch
+            unsigned l2;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+            AttnTile<NT, DKS, DT> t1 = t;
+            t1.fq = (int)(l2 & 15u);
+            t1.fg = (int)(l2 >> 4);
+            attn_blocks<NT, DKS, DT, 1, DHR>(t1, nqb - 1);
+        }
     } else {
         for (int qb = slot; qb < nqb; qb += nslot) attn_blocks<NT, DKS, DT, 1, DHR>(t, qb);
     }
