@@ -420,6 +420,12 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
     }
 }
 
+// CLIP_AMD_GEMM8P=0: never pick the persistent 8-wave kernel by heuristic (A/B runs; an explicit tile code 160257 still reaches it)
+bool gemm8p_enabled() {
+    static const bool on = [] { const char * e = getenv("CLIP_AMD_GEMM8P"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // Tile heuristic, fitted to scripts/gemm_bench.py measurements (profiles/README.md).  Small problems take the smallest
 // tiles (most workgroups).  Otherwise BN = 128 and BM in {64, 128, 160, 192} minimising
 //     g(tiles / 512) x (BM + 32)            [x 1.15 for BM = 64]
@@ -427,9 +433,15 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
 // one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
-int pick_tile(int M, int N, int Kpad, bool quantised) {
+int pick_tile(int M, int N, int Kpad, bool quantised, int epilogue = -1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
+    // fp16-output GEMMs (q/k/v, FFN-up) of a large batch on an fp16 weight (an f16 file, or a resident panel: forward.cpp resident_panels):
+    // the persistent 8-wave kernel (k_gemm8p.hip) — from one full round of 160 x 256 tiles up to four tiles per workgroup
+    if (!quantised && gemm8p_enabled() && gemm8p_supported(Kpad, epilogue) && M < 32768) {
+        const int t8 = wgs(160, 256);
+        if (t8 >= 256 && t8 <= 4 * 256) return 160257;
+    }
     if (M <= 4096) {
         // mid-M (a few hundred to a few thousand rows: batches of 2-64 ViT-B/32 images, batches of texts, single ViT-L/14 images): the
         // ring kernel of k_gemm_ring.hip where the sweep of profiles/r02_ring_sweep_*.txt (M = 130 ... 3200 x the model widths, q4_0 and
@@ -497,7 +509,7 @@ void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
-int gemm_tile_for(int M, int N, int Kpad, bool quantised) { return pick_tile(M, N, Kpad, quantised); }
+int gemm_tile_for(int M, int N, int Kpad, bool quantised, int epilogue) { return pick_tile(M, N, Kpad, quantised, epilogue); }
 
 // LayerNorm fold: columns per statistics slot written by the residual epilogue of the kernel behind a tile code (fold_slotw<TN>() of
 // gemm_common.h: 64 where a wave spans >= 64 columns — the BN = 128 tiles of this file, k_gemm8.hip, k_gemm4.hip —, else 32)
@@ -545,7 +557,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         p.W.wtype = W_F16;
         p.W.w16 = p.w16_pre;
     }
-    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
+    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16, epilogue);
     if (tile % 1000 == 258 || tile % 1000 == 260) {
         // 256 x 256 tiles in whole rounds: one workgroup per CU means a launch costs ceil(tiles / 256) rounds, and ViT-L/14's
         // 65792 rows are 257 tile rows — one past a round boundary for every N.  The leading tile rows that fill whole rounds go to
@@ -588,6 +600,10 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
+            if (tile % 1000 == 257) {
+                if (launch_gemm8p(p, epilogue, stream)) return;
+                tile = 160256;                     // (shape / epilogue / depth outside the persistent kernel's instantiations)
+            }
             if (tile % 1000 == 259 && !p.ln_c && !p.xg_out) {
                 launch_gemm4(p, epilogue, stream);
                 return;

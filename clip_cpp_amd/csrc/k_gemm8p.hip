@@ -19,9 +19,9 @@
 //     part, outside the K loop, so the loop's counted vmcnt waits see only LDS-DMA requests and the (older) stores.  The row
 //     statistics are reduced per WAVE for its own 80 rows (4 x redundant loads of a few KB) and handed round with ds_bpermute —
 //     no workgroup barrier in the epilogue, the two M-groups keep their one-barrier stagger across tiles.
-// Needs the weight as an fp16 panel (k_gemm8.hip dequant_kernel; forward.cpp keeps the panels of these two weights resident) and
-// Kpad / 64 a multiple of 3 (the stage of a K-tile is then a compile-time constant: K = 768 — ViT-B/32 and the ViT-L/14 text tower —
-// 1536, 2304; other depths stay on the kernels of k_gemm8.hip / k_gemm.hip).
+// Needs the weight as an fp16 panel (k_gemm8.hip dequant_kernel; forward.cpp keeps the panels of these two weights resident).  The K
+// loop is fully unrolled per output tile (the store slots and the switch of sources are then compile-time positions), so it is
+// instantiated per depth: K = 512, 768, 1024, 1280 (the hidden sizes of the CLIP towers); other depths stay on k_gemm8.hip / k_gemm.hip.
 
 #include "gemm_common.h"
 
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
     constexpr int NX = XF + (XR ? 1 : 0);             // X requests per wave per K-tile
     constexpr int NW = 4;                             // W requests per wave per K-tile (32 rows)
     static_assert(3 * STAGE <= 160 * 1024, "three-stage ring does not fit the LDS");
-    static_assert(KT % 3 == 0 && KT >= 6, "the stage of a K-tile must not depend on the output tile");
+    static_assert(KT >= 6, "at least two K-tiles of slack for the deferred stores");
     static_assert(EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16, "fp16-output epilogues only");
     constexpr int NFR = TN * TM;                      // fragments (packed fp16 register pairs) per lane and tile
     constexpr int FPK = (NFR + KT - 3) / (KT - 2);    // stores per K-tile: the tile is out before the next tile's last two K-tiles
@@ -106,14 +106,14 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
 #define P_ISSUE_W(st_, S_, kt_)                                                                                   \
     {                                                                                                             \
         _Pragma("unroll") for (int j = 0; j < NW; j++)                                                            \
-            PGLDS16(Wb + (S_).w[j] + (uint32_t)((kt_) * BK * 2), smem + (st_) * STAGE + XB + (wave * 32 + 8 * j) * 128); \
+            PGLDS16(Wb + (S_).w[j] + (uint32_t)((kt_) * BK * 2), smem + so[st_] + XB + (wave * 32 + 8 * j) * 128); \
     }
 #define P_ISSUE_X(st_, S_, kt_)                                                                                   \
     {                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < XF; i++)                                                            \
-            PGLDS16(Ab + (S_).x[i] + (uint32_t)((kt_) * BK * 2), smem + (st_) * STAGE + (wave * RPW + 8 * i) * 128); \
+            PGLDS16(Ab + (S_).x[i] + (uint32_t)((kt_) * BK * 2), smem + so[st_] + (wave * RPW + 8 * i) * 128); \
         if constexpr (XR != 0) {                                                                                  \
-            if (lane < 32) PGLDS16(Ab + (S_).x[XF] + (uint32_t)((kt_) * BK * 2), smem + (st_) * STAGE + (wave * RPW + 8 * XF) * 128); \
+            if (lane < 32) PGLDS16(Ab + (S_).x[XF] + (uint32_t)((kt_) * BK * 2), smem + so[st_] + (wave * RPW + 8 * XF) * 128); \
         }                                                                                                         \
     }
     // fragment read addresses (bytes inside a stage): k-slice 0 reads chunk fgrp, k-slice 1 chunk 4 + fgrp -> offset ^ 64
@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
     const int lw = XB + (wn * 64 + frow) * 128;       // + a * 2048
     const int lx = (wm * TM * 16 + frow) * 128;       // + b * 2048
 
+    // byte offsets of the three ring stages as the CURRENT output tile sees them: K-tile t of a tile lives in so[t % 3].  The K-tiles of
+    // successive tiles are one stream, so for KT % 3 != 0 the assignment rotates by KT % 3 from tile to tile (uniform values: SGPRs)
+    int so[3] = {0, STAGE, 2 * STAGE};
     f4 acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; a++)
@@ -134,7 +137,7 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
 
 #define P_READ_FRAGS(st_, kk_)                                                                                    \
     {                                                                                                             \
-        const unsigned char * sb = smem + (st_) * STAGE;                                                          \
+        const unsigned char * sb = smem + so[st_];                                                                \
         const int so = (kk_) ? (sw ^ 64) : sw;                                                                    \
         _Pragma("unroll") for (int a = 0; a < TN; a++) wf[a] = *(const h8 *)(sb + lw + a * 2048 + so);            \
         _Pragma("unroll") for (int b = 0; b < TM; b++) xf[b] = *(const h8 *)(sb + lx + b * 2048 + so);            \
@@ -308,6 +311,8 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
 #pragma unroll
             for (int q = 0; q < QP; q++) stq[k][q] = stq[k + 1][q];
         v = vn; m0 = m0n; n0 = n0n;
+        if constexpr (KT % 3 == 1) { const int t0 = so[0]; so[0] = so[1]; so[1] = so[2]; so[2] = t0; }
+        if constexpr (KT % 3 == 2) { const int t0 = so[0]; so[0] = so[2]; so[2] = so[1]; so[1] = t0; }
     }
     // the last tile of this workgroup: all of its stores at once
 #pragma unroll
@@ -364,18 +369,32 @@ bool launch8p_epi(const GemmParams & p, int epi, hipStream_t stream) {
 
 }  // namespace
 
+static bool launch8p_depth(const GemmParams & p, int epilogue, hipStream_t stream);
+
 // the persistent kernel takes this launch: fp16-output epilogue, fp16 panel in p.W.w16, K depth one of the instantiated ones
 bool gemm8p_supported(int Kpad, int epilogue) {
     const bool f16out = epilogue == EPI_F16 || epilogue == EPI_GELU_F16 || epilogue == EPI_QGELU_F16;
-    return f16out && (Kpad == 768 || Kpad == 1536);
+    return f16out && (Kpad == 512 || Kpad == 768 || Kpad == 1024 || Kpad == 1280);
 }
+
+static unsigned long long g_gemm8p_launches = 0;      // (test hook: proves that a launch really took this kernel and not its fallback)
+unsigned long long gemm8p_launch_count() { return g_gemm8p_launches; }
 
 bool launch_gemm8p(const GemmParams & p, int epilogue, hipStream_t stream) {
     if (!gemm8p_supported(p.W.Kpad, epilogue) || p.W.wtype != W_F16 || !p.W.w16) return false;
     if ((p.ldc & 3) != 0) return false;               // 8-byte stores
+    if ((unsigned long long)p.M * (unsigned)p.lda * 2ull >= (1ull << 32) || (unsigned long long)p.W.Npad * (unsigned)p.W.Kpad * 2ull >= (1ull << 32)) return false;   // 32-bit source offsets
+    const bool ok = launch8p_depth(p, epilogue, stream);
+    if (ok) g_gemm8p_launches++;
+    return ok;
+}
+
+static bool launch8p_depth(const GemmParams & p, int epilogue, hipStream_t stream) {
     switch (p.W.Kpad / BK) {
-    case 12: return launch8p_epi<5, 12>(p, epilogue, stream);
-    case 24: return launch8p_epi<5, 24>(p, epilogue, stream);
+    case 8: return launch8p_epi<5, 8>(p, epilogue, stream);        // K = 512: ViT-B/32 text tower
+    case 12: return launch8p_epi<5, 12>(p, epilogue, stream);      // K = 768: ViT-B/32 vision, ViT-L/14 text
+    case 16: return launch8p_epi<5, 16>(p, epilogue, stream);      // K = 1024: ViT-L/14 vision, ViT-H/14 text
+    case 20: return launch8p_epi<5, 20>(p, epilogue, stream);      // K = 1280: ViT-H/14 vision
     }
     return false;
 }
