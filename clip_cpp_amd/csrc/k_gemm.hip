@@ -420,9 +420,9 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
     }
 }
 
-// CLIP_AMD_GEMM8P=0: never pick the persistent 8-wave kernel by heuristic (A/B runs; an explicit tile code 160257 still reaches it)
-bool gemm8p_enabled() {
-    static const bool on = [] { const char * e = getenv("CLIP_AMD_GEMM8P"); return !(e && e[0] == '0'); }();
+// CLIP_AMD_GEMM4_F16OUT=0: the fp16-output GEMMs of mid-size batches stay off the four-wave 256 x 256 kernel (A/B runs)
+bool gemm4_f16out_enabled() {
+    static const bool on = [] { const char * e = getenv("CLIP_AMD_GEMM4_F16OUT"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -436,11 +436,16 @@ bool gemm8p_enabled() {
 int pick_tile(int M, int N, int Kpad, bool quantised, int epilogue = -1) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
-    // fp16-output GEMMs (q/k/v, FFN-up) of a large batch on an fp16 weight (an f16 file, or a resident panel: forward.cpp resident_panels):
-    // the persistent 8-wave kernel (k_gemm8p.hip) — from one full round of 160 x 256 tiles up to four tiles per workgroup
-    if (!quantised && gemm8p_enabled() && gemm8p_supported(Kpad, epilogue) && M < 32768) {
-        const int t8 = wgs(160, 256);
-        if (t8 >= 256 && t8 <= 4 * 256) return 160257;
+    // fp16-output GEMMs (q/k/v, FFN-up) of a large batch on an fp16 weight (an f16 file, or a resident panel: forward.cpp resident_panels)
+    // whose 256 x 256 tiles fill their rounds of 256 workgroups: the four-wave 128 x 128-per-wave kernel (k_gemm4.hip; consumer half of the
+    // LayerNorm fold since round 5).  Same-box, 200 launches, plain / fold form (profiles/r05/): ViT-B/32 q/k/v 12800 x 2304 x 768 (450 tiles,
+    // 1.76 rounds) 57.3 us against 64.1 for the 160 x 128 fused tile, text q/k/v 10290 x 1536 x 512 (246 tiles) 25.7 against 29.4-33.1;
+    // FFN-up (600 / 328 tiles: 2.3 / 1.3 rounds) is level or behind and stays where it is.
+    if (!quantised && gemm4_f16out_enabled() && (epilogue == EPI_F16 || epilogue == EPI_GELU_F16 || epilogue == EPI_QGELU_F16) && M >= 8192 && M < 32768 &&
+        Kpad <= 1280) {
+        const int t4 = wgs(256, 256);
+        const float rounds = (float)t4 / 256.f, eff = rounds / ceilf(rounds);
+        if (t4 >= 230 && eff >= 0.85f) return 256259;
     }
     if (M <= 4096) {
         // mid-M (a few hundred to a few thousand rows: batches of 2-64 ViT-B/32 images, batches of texts, single ViT-L/14 images): the
@@ -604,7 +609,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
                 if (launch_gemm8p(p, epilogue, stream)) return;
                 tile = 160256;                     // (shape / epilogue / depth outside the persistent kernel's instantiations)
             }
-            if (tile % 1000 == 259 && !p.ln_c && !p.xg_out) {
+            if (tile % 1000 == 259 && !p.xg_out) {      // (consumer half of the LayerNorm fold: in the kernel since round 5)
                 launch_gemm4(p, epilogue, stream);
                 return;
             }

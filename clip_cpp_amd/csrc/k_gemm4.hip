@@ -163,6 +163,19 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
         _Pragma("unroll") for (int b = 0; b < TM; b++) XF_[b] = *(const h8 *)(sb + lx + b * 2048 + swz_);           \
     }
 
+    // CONSUMER half of the LayerNorm fold (round 5; gemm_common.h): thread t reduces the statistics of row m0 + t to (mean - mu, rstd) before
+    // the first request and parks the pair in LDS BEHIND the ring (2 KB at 128 KB) — nothing is carried in registers through the K loop, the
+    // fp16 epilogues pick the rows' pairs up from there (any of the loop's barriers orders the two).  The producer half (xg + statistics out of
+    // the residual epilogue) stays out of this kernel: beside 256 accumulators it spilled 196 registers (profiles/HISTORY.md, r04).
+    constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
+    float2 * const ln_rs = (float2 *)(smem + 2 * STAGE);
+    const bool ln = LNE && p.ln_c != nullptr;
+    if constexpr (LNE) {
+        if (ln) {
+            ln_rs[tid] = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, n0 == 0 && m0 + tid < p.M);
+            __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0), as a builtin: hipcc's own counting restarts from zero
+        }
+    }
     f4 acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; a++)
@@ -235,19 +248,29 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();
 #endif
     const int nb = n0 + wn * 128, mb = m0 + wm * 128;
-    // (no LayerNorm fold in this kernel: FOLD = false — gemm_common.h; launch_gemm sends folded launches to the 8-wave 256 x 256 tile)
+    // the lane coordinates are derived again for the epilogue (v_mbcnt, opaque to CSE): the K loop uses all 256 VGPRs, and a value kept
+    // across it only for the epilogue's sake is spilled to scratch
+    unsigned lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int frow_e = (int)(lane_e & 15u), fgrp_e = (int)(lane_e >> 4), lane_i = (int)lane_e;
+    // (LayerNorm fold: the consumer half only — rs_lane: this lane's rows of the pairs parked in the prologue; the producer half of the
+    //  residual epilogue is compiled out, FOLD = false there: launch_gemm sends producer launches to the 8-wave 256 x 256 tile)
+    const float2 * rs_lane = ln_rs + wm * 128 + frow_e;
     bool done = false;
-    if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
+    if constexpr (LNE) {
         if (nb + 128 <= p.W.N && (p.ldc & 7) == 0) {
             raw_barrier4();                            // every wave is done with the ring: it becomes the staging area
             half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
             typedef f4 half_acc_t[4][TM];
-            gemm_epilogue_f16_staged<EPI, 4, TM, false>(p, *(half_acc_t *)&acc[0], nb, mb, frow, fgrp, stage, lane, false, nullptr);
-            gemm_epilogue_f16_staged<EPI, 4, TM, false>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow, fgrp, stage, lane, false, nullptr);
+            gemm_epilogue_f16_staged<EPI, 4, TM, true>(p, *(half_acc_t *)&acc[0], nb, mb, frow_e, fgrp_e, stage, lane_i, ln, rs_lane);
+            gemm_epilogue_f16_staged<EPI, 4, TM, true>(p, *(half_acc_t *)&acc[4], nb + 64, mb, frow_e, fgrp_e, stage, lane_i, ln, rs_lane);
             done = true;
         }
     }
-    if (!done) gemm_epilogue<EPI, TN, TM, false>(p, acc, nb, mb, frow, fgrp, false, nullptr);
+    if (!done) {
+        if constexpr (LNE) gemm_epilogue<EPI, TN, TM, true>(p, acc, nb, mb, frow_e, fgrp_e, ln, rs_lane);
+        else gemm_epilogue<EPI, TN, TM, false>(p, acc, nb, mb, frow_e, fgrp_e, false, nullptr);
+    }
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();       // stores issued (not necessarily landed)
@@ -261,7 +284,7 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
 template <int EPI>
 void launch4(const GemmParams & p, hipStream_t stream) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.W.N + 255) / 256;
-    constexpr size_t smem = (size_t)2 * 512 * 128;   // the ring (128 KB); the fp16 staging (4 x 17 KB) lies inside it
+    constexpr size_t smem = (size_t)2 * 512 * 128 + 256 * sizeof(float2);   // the ring (128 KB; the fp16 staging, 4 x 17 KB, lies inside it) + the row statistics of the LayerNorm fold
     static unsigned long long lds_ok = 0;
     opt_in_dynamic_lds(gemm4_kernel<EPI>, smem, lds_ok);
     hipLaunchKernelGGL((gemm4_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(NT4), smem, stream, p);

@@ -135,8 +135,24 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TM; b++) outp[a][b] = make_uint2(0u, 0u);
 
+#ifdef CLIPAMD_ABLATION   // tuning builds (scripts/build_variant.sh NAME -DCLIPAMD_ABLATION): p.debug bit 0 no LDS-DMA in the loop, 1 no MFMA, 2 no fragment reads, 3 no stores, 4 no epilogue arithmetic
+    const bool ab_nodma = p.debug & 1, ab_nomfma = p.debug & 2, ab_noread = p.debug & 4, ab_nostore = p.debug & 8, ab_noepi = p.debug & 16;
+#define PAB_DMA if (!ab_nodma)
+#define PAB_READ if (!ab_noread)
+#define PAB_MFMA if (!ab_nomfma)
+#define PAB_STORE if (!ab_nostore)
+#define PAB_EPI if (!ab_noepi)
+#define PAB_INIT _Pragma("unroll") for (int a = 0; a < TN; a++) wf[a] = (h8)(_Float16)1.0f; _Pragma("unroll") for (int b = 0; b < TM; b++) xf[b] = (h8)(_Float16)1.0f;
+#else
+#define PAB_DMA
+#define PAB_READ
+#define PAB_MFMA
+#define PAB_STORE
+#define PAB_EPI
+#define PAB_INIT
+#endif
 #define P_READ_FRAGS(st_, kk_)                                                                                    \
-    {                                                                                                             \
+    PAB_READ {                                                                                                    \
         const unsigned char * sb = smem + so[st_];                                                                \
         const int so = (kk_) ? (sw ^ 64) : sw;                                                                    \
         _Pragma("unroll") for (int a = 0; a < TN; a++) wf[a] = *(const h8 *)(sb + lw + a * 2048 + so);            \
@@ -147,7 +163,7 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
         p_wait_lgkm0();                                                                                           \
         p_barrier();                                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int a = 0; a < TN; a++)                                                            \
+        PAB_MFMA _Pragma("unroll") for (int a = 0; a < TN; a++)                                                   \
             _Pragma("unroll") for (int b = 0; b < TM; b++)                                                        \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);             \
         __builtin_amdgcn_s_setprio(0);                                                                            \
@@ -236,8 +252,9 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
             }
             const bool more = (t + 2 < KT) || has_next;
             h8 wf[TN], xf[TM];
+            PAB_INIT
             if (more) {
-                P_ISSUE_W(SR, cur, t + 2 < KT ? t + 2 : t + 2 - KT);
+                PAB_DMA P_ISSUE_W(SR, cur, t + 2 < KT ? t + 2 : t + 2 - KT);
             }
             P_READ_FRAGS(ST, 0);
             P_MFMA_SEGMENT();
@@ -245,7 +262,7 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
             // previous K-tile's slot, which are older than those requests (issued BEFORE the X requests below for exactly this reason:
             // the immediate of this wait must not depend on whether a slot had something to store)
             if (more) p_wait_vmcnt<NW>(); else p_wait_vmcnt<0>();
-            if (have_prev) {
+            PAB_STORE if (have_prev) {
 #pragma unroll
                 for (int f = t * FPK; f < (t + 1) * FPK && f < NFR; f++) {
                     const int b = f / TN, a = f % TN;  // the four column strips of a row block in consecutive slots: full 128-byte lines meet in L2
@@ -254,14 +271,14 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
                 }
             }
             if (more) {
-                P_ISSUE_X(SR, cur, t + 2 < KT ? t + 2 : t + 2 - KT);
+                PAB_DMA P_ISSUE_X(SR, cur, t + 2 < KT ? t + 2 : t + 2 - KT);
             }
             P_READ_FRAGS(ST, 1);
             P_MFMA_SEGMENT();
         }
         // ---- arithmetic half of the epilogue: acc -> packed fp16 registers.  The only place with loads that return to registers. ----
         const int nb = n0 + wn * 64, mb = m0 + wm * TM * 16;
-        {
+        PAB_EPI {
             f4 biasv[TN], cv[TN];                      // requested first: in flight under the statistics passes
 #pragma unroll
             for (int a = 0; a < TN; a++) {
@@ -315,6 +332,7 @@ __global__ void __launch_bounds__(NT8P, 2) gemm8p_kernel(const GemmParams p) {
         if constexpr (KT % 3 == 2) { const int t0 = so[0]; so[0] = so[2]; so[2] = so[1]; so[1] = t0; }
     }
     // the last tile of this workgroup: all of its stores at once
+    PAB_STORE
 #pragma unroll
     for (int b = 0; b < TM; b++) {
 #pragma unroll

@@ -668,7 +668,7 @@ def test_lnfold_is_bitwise_independent_of_the_producer_and_consumer_kernels(L, t
     tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2)
     for fold in (1, 2):            # 2: the centred operand (per-row offsets): the same invariance
         base = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, 64128, 64128, fold)[1]
-        for t1, t2 in [(64064, 64128), (65064, 64128), (65128, 128128), (160128, 65064), (192128, 65128), (160256, 160128), (256259, 256256), (128064, 128064)]:
+        for t1, t2 in [(64064, 64128), (65064, 64128), (65128, 128128), (160128, 65064), (192128, 65128), (160256, 160128), (256259, 256256), (128064, 128064), (160128, 256259), (65064, 256260)]:     # 256259 / 256260 as consumer: k_gemm4.hip (consumer half of the fold, round 5)
             y = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, 2, t1, t2, fold)[1]
             assert np.array_equal(base, y), "fold %d tiles (%d, %d): %s" % (fold, t1, t2, _diff_report(base, y))
 
