@@ -66,7 +66,7 @@ AMD_SYMBOLS = [
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
-    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_gemm_tile", "clip_amd_test_gemm8p_launches", "clip_amd_test_skinny", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
+    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_gemm_tile", "clip_amd_test_skinny", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
 
 _lib = None
@@ -171,8 +171,6 @@ def lib():
                                        i32, i32, i32, i32, i32, C.c_float, f32p, f32p]
     L.clip_amd_test_gemm_tile.restype = i32
     L.clip_amd_test_gemm_tile.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32]
-    L.clip_amd_test_gemm8p_launches.restype = C.c_longlong
-    L.clip_amd_test_gemm8p_launches.argtypes = []
     L.clip_amd_test_skinny.restype = i32
     L.clip_amd_test_skinny.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_float, f32p, i32, i32, C.c_float, f32p]
     L.clip_amd_bench_gemm.restype = C.c_float

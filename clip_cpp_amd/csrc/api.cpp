@@ -663,8 +663,6 @@ int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches,
 #define CLIPAMD_TEST_HOOKS 1
 #endif
 #if CLIPAMD_TEST_HOOKS
-long long clip_amd_test_gemm8p_launches(void) { return (long long)gemm8p_launch_count(); }
-
 int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised) {
     const int Kpad = (int)((K + 63) / 64 * 64);
     return gemm_tile_for((int)M, (int)N, Kpad, quantised != 0);

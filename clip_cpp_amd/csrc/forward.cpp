@@ -122,7 +122,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
         return;
     }
     const int wt = p.w16_pre ? (int)W_F16 : p.W.wtype;       // a dequantised panel is multiplied as an f16 weight (launch_gemm)
-    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, wt != W_F16, epi);
+    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, wt != W_F16);
     const bool panel = gemm_tile_uses_panel(tile) && wt == W_F16;
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double wb = wt == W_F16 ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);
@@ -130,8 +130,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
                       + (p.xg_out ? (double)p.M * p.W.N * 2 : 0.0);     // LayerNorm fold: the residual epilogue also writes the next GEMM's fp16 operand
     // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
-    if (panel && tile % 1000 == 257) snprintf(fam, sizeof fam, "gemm8p_kernel<5,%d,%d>/%s", epi, p.W.Kpad / 64, what);   // persistent 8-wave kernel (k_gemm8p.hip; explicit tile code only)
-    else if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
+    if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
     else if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
     else if (gemm_tile_is_ring(tile)) snprintf(fam, sizeof fam, "gemm_ring_kernel<%d,%d,4,%d,%d>/%s", wt, tile % 1000, tile % 1000 >= 128 ? 4 : 2, epi, what);
     else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", wt, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
@@ -476,11 +475,6 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
     const DevLayer & l0 = tw.layers[0];
     unsigned want = 0;
     if (l0.ff2.wtype != W_F16 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
-    // round 5: q/k/v (and FFN-up) where the heuristic gives the fp16-output GEMM of this batch, multiplied as an fp16 weight, to a panel
-    // kernel — the four-wave 256 x 256 kernel when its tiles fill their rounds (k_gemm.hip pick_tile)
-    const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
-    if (l0.qkv.wtype != W_F16 && rows < 32768 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.qkv.N, l0.qkv.Kpad, false, EPI_F16))) want |= 1u;
-    if (l0.ff1.wtype != W_F16 && rows < 32768 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff1.N, l0.ff1.Kpad, false, act))) want |= 4u;
     if (!want) return nullptr;
     auto & tab = ctx->res_panels[which];
     if ((ctx->res_panel_mask[which] & want) == want && tab.size() == 4 * tw.layers.size()) return tab.data();

@@ -420,12 +420,6 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
     }
 }
 
-// CLIP_AMD_GEMM4_F16OUT=0: the fp16-output GEMMs of mid-size batches stay off the four-wave 256 x 256 kernel (A/B runs)
-bool gemm4_f16out_enabled() {
-    static const bool on = [] { const char * e = getenv("CLIP_AMD_GEMM4_F16OUT"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 // Tile heuristic, fitted to scripts/gemm_bench.py measurements (profiles/README.md).  Small problems take the smallest
 // tiles (most workgroups).  Otherwise BN = 128 and BM in {64, 128, 160, 192} minimising
 //     g(tiles / 512) x (BM + 32)            [x 1.15 for BM = 64]
@@ -433,20 +427,13 @@ bool gemm4_f16out_enabled() {
 // not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
 // one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
-int pick_tile(int M, int N, int Kpad, bool quantised, int epilogue = -1) {
+int pick_tile(int M, int N, int Kpad, bool quantised) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return 64064;
-    // fp16-output GEMMs (q/k/v, FFN-up) of a large batch on an fp16 weight (an f16 file, or a resident panel: forward.cpp resident_panels)
-    // whose 256 x 256 tiles fill their rounds of 256 workgroups: the four-wave 128 x 128-per-wave kernel (k_gemm4.hip; consumer half of the
-    // LayerNorm fold since round 5).  Same-box, 200 launches, plain / fold form (profiles/r05/): ViT-B/32 q/k/v 12800 x 2304 x 768 (450 tiles,
-    // 1.76 rounds) 57.3 us against 64.1 for the 160 x 128 fused tile, text q/k/v 10290 x 1536 x 512 (246 tiles) 25.7 against 29.4-33.1;
-    // FFN-up (600 / 328 tiles: 2.3 / 1.3 rounds) is level or behind and stays where it is.
-    if (!quantised && gemm4_f16out_enabled() && (epilogue == EPI_F16 || epilogue == EPI_GELU_F16 || epilogue == EPI_QGELU_F16) && M >= 8192 && M < 32768 &&
-        Kpad <= 1280) {
-        const int t4 = wgs(256, 256);
-        const float rounds = (float)t4 / 256.f, eff = rounds / ceilf(rounds);
-        if (t4 >= 230 && eff >= 0.85f) return 256259;
-    }
+    // (round 5, measured and NOT done — profiles/r05_experiments.txt: the fp16-output GEMMs of the ViT-B/32 batch on resident fp16 panels and the
+    //  four-wave 256 x 256 kernel — isolated q/k/v 57.3 us against 64.1, text q/k/v 25.7 against 29.4 — leave the vision q/k/v launch of the
+    //  layer chain where it was (0.791 against 0.798 ms per step) and cost the two-tower step 1.5 %: 130 KB workgroups keep the other tower's
+    //  kernels off the CUs.  The same for a persistent 8-wave kernel with its stores deferred under the next tile's K loop: level at best.)
     if (M <= 4096) {
         // mid-M (a few hundred to a few thousand rows: batches of 2-64 ViT-B/32 images, batches of texts, single ViT-L/14 images): the
         // ring kernel of k_gemm_ring.hip where the sweep of profiles/r02_ring_sweep_*.txt (M = 130 ... 3200 x the model widths, q4_0 and
@@ -514,7 +501,7 @@ void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
-int gemm_tile_for(int M, int N, int Kpad, bool quantised, int epilogue) { return pick_tile(M, N, Kpad, quantised, epilogue); }
+int gemm_tile_for(int M, int N, int Kpad, bool quantised) { return pick_tile(M, N, Kpad, quantised); }
 
 // LayerNorm fold: columns per statistics slot written by the residual epilogue of the kernel behind a tile code (fold_slotw<TN>() of
 // gemm_common.h: 64 where a wave spans >= 64 columns — the BN = 128 tiles of this file, k_gemm8.hip, k_gemm4.hip —, else 32)
@@ -562,7 +549,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         p.W.wtype = W_F16;
         p.W.w16 = p.w16_pre;
     }
-    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16, epilogue);
+    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
     if (tile % 1000 == 258 || tile % 1000 == 260) {
         // 256 x 256 tiles in whole rounds: one workgroup per CU means a launch costs ceil(tiles / 256) rounds, and ViT-L/14's
         // 65792 rows are 257 tile rows — one past a round boundary for every N.  The leading tile rows that fill whole rounds go to
@@ -605,10 +592,6 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
-            if (tile % 1000 == 257) {
-                if (launch_gemm8p(p, epilogue, stream)) return;
-                tile = 160256;                     // (shape / epilogue / depth outside the persistent kernel's instantiations)
-            }
             if (tile % 1000 == 259 && !p.xg_out) {      // (consumer half of the LayerNorm fold: in the kernel since round 5)
                 launch_gemm4(p, epilogue, stream);
                 return;

@@ -119,14 +119,12 @@ struct GemmParams {
 // BM = 65: the ring kernel of k_gemm_ring.hip on 64-row tiles, BN in {64,128};
 // BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
-// the tile (BM*1000+BN) the heuristic picks for this shape; epilogue (an Epilogue value, or -1 = unknown) lets it pick the persistent
-// 8-wave kernel of k_gemm8p.hip (BN code 257) for the fp16-output GEMMs
-int gemm_tile_for(int M, int N, int Kpad, bool quantised, int epilogue = -1);
+int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
 // the shape runs on a large-M kernel that multiplies an fp16 W panel (k_gemm8.hip / k_gemm4.hip).  BN codes: 256 plain 8-wave tile
-// (BM 96 / 128 / 160 / 256), 257 the PERSISTENT 8-wave 160 x 256 kernel of k_gemm8p.hip (fp16-output epilogues), 258 the 8-wave 256 x 256 tile on the rows that fill whole rounds of 256 workgroups + a second launch for the
+// (BM 96 / 128 / 160 / 256), 258 the 8-wave 256 x 256 tile on the rows that fill whole rounds of 256 workgroups + a second launch for the
 // rest, 259 the 4-wave 256 x 256 tile (k_gemm4.hip), 260 = 259 with the whole-rounds split
 inline bool gemm_tile_is_ring(int tile) { return (tile % 1000000) / 1000 == 65; }   // k_gemm_ring.hip (BM code 65)
-inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return !gemm_tile_is_ring(tile) && (bn >= 256 && bn <= 260); }
+inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return !gemm_tile_is_ring(tile) && (bn == 256 || (bn >= 258 && bn <= 260)); }
 
 // k_gemm_ring.hip: mid-M GEMM (64 activation rows x bn weight rows per workgroup, bn in {64, 128}; a 3-4 stage LDS ring of K-tiles
 // filled by LDS-DMA only, block-quantised weights staged raw and dequantised per MFMA fragment; split-K as k_gemm.hip: p.ksplit).
@@ -135,12 +133,6 @@ void launch_gemm_ring(const GemmParams & p, int epilogue, int bn, hipStream_t st
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);
-// k_gemm8p.hip: persistent form of the 8-wave kernel for the fp16-output epilogues (tile code 160257): one workgroup per CU walks its
-// tiles, the K-tiles of successive tiles are one stream through the LDS ring and a tile's stores are issued under the next tile's K loop.
-// false = shape / epilogue / depth not covered (the caller launches another kernel).
-bool gemm8p_supported(int Kpad, int epilogue);
-bool launch_gemm8p(const GemmParams & p, int epilogue, hipStream_t stream);
-unsigned long long gemm8p_launch_count();   // launches taken by the persistent kernel so far (process-wide; test hook)
 // k_gemm4.hip: 4 waves x (128 x 128) on 256 x 256 tiles, accumulators in AGPRs, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel)
 void launch_gemm4(const GemmParams & p, int epilogue, hipStream_t stream);
 // dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)

@@ -159,9 +159,6 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
 /* The tile the heuristic of launch_gemm picks for an [M][K] x [N][K]^T problem (pure host arithmetic, no device needed):
  * BM * 1000 + BN; BM = 65: the mid-M ring kernel on 64-row tiles (k_gemm_ring.hip), BN = 256 / 258-260: the large-M panel kernels. */
 int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised);
-/* Number of GEMM launches the persistent 8-wave kernel (k_gemm8p.hip, tile code 160257) has taken in this process: lets a test assert
- * that a launch ran on it and not on its fallback. */
-long long clip_amd_test_gemm8p_launches(void);
 /* Average device time (microseconds, HIP events) of one GEMM shape through the production kernel on random
  * weights of ggml type `type`; < 0 on error.  Used by scripts/gemm_bench.py for kernel A/B work. */
 float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters);

@@ -16,7 +16,6 @@ done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm_ring.hip -o $V/k_gemm_ring.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm.hip -o $V/k_gemm.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm8.hip -o $V/k_gemm8.hip.o &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm8p.hip -o $V/k_gemm8p.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm4.hip -o $V/k_gemm4.hip.o &
 wait
 OBJS=$(ls $B/*.o | grep -v 'k_gemm')

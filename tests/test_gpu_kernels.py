@@ -391,69 +391,6 @@ def test_gemm8_ring_lengths_and_epilogues_match_the_4_wave_kernel_bitwise(L, til
     assert np.array_equal(y, y2)
 
 
-@pytest.mark.parametrize("K,tname,epi", [(768, "q4_0", 3), (768, "f16", 1), (512, "q4_0", 1), (512, "q8_0", 3), (1024, "f16", 2), (1024, "q5_1", 1), (1280, "q8_0", 3)])
-def test_gemm8p_persistent_kernel_is_bitwise_the_tiled_kernels(L, K, tname, epi):
-    """Persistent 8-wave kernel (k_gemm8p.hip, tile code 160257; round 5): one workgroup per CU walks several output tiles, their K-tiles
-    form one stream through the 3-stage LDS ring (stage assignment rotating by K-tiles % 3 from tile to tile: 8, 12, 16, 20 K-tiles cover the
-    three residues), a tile's stores are issued from registers under the NEXT tile's K loop.  More tiles than workgroups (2-3 per
-    workgroup), M and N edges inside a tile, the Q-scale columns, every fp16 epilogue: bit for bit the 128 x 128 tile of the 4-wave
-    kernel, run to run; and the launch counter proves the persistent kernel — not its fallback — took the launches."""
-    rng = np.random.default_rng(K + epi)
-    M, N = 6000 + 37, 4096 - 64                # 38 x 16 = 608 tiles of 160 x 256 on 256 workgroups; last row tile 117 rows, last column tile 192 columns
-    tid = ref.GGML_TYPES[tname]
-    raw = ref.quantize(tid, _weights(rng, N, K) * 3)
-    X = rng.standard_normal((M, K)).astype(np.float32)
-    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
-    qc, qs = (1344, 0.125) if epi == 1 else (0, 1.0)
-    base = run_gemm_ex(L, tid, raw, N, K, X, bias=bias, epi=epi, tile=128128, qcols=qc, qscale=qs)
-    n0 = L.clip_amd_test_gemm8p_launches()
-    for rep in range(3):
-        y = run_gemm_ex(L, tid, raw, N, K, X, bias=bias, epi=epi, tile=160257, qcols=qc, qscale=qs)
-        assert np.all(np.isfinite(y))
-        assert np.array_equal(base, y), (rep, _diff_report(base, y))
-    assert L.clip_amd_test_gemm8p_launches() == n0 + 3
-    # fewer tiles than workgroups (one tile each, no stream across tiles), and a single row
-    for Ms in (700, 1):
-        b2 = run_gemm_ex(L, tid, raw, N, K, X[:Ms], bias=bias, epi=epi, tile=128128, qcols=qc, qscale=qs)
-        y2 = run_gemm_ex(L, tid, raw, N, K, X[:Ms], bias=bias, epi=epi, tile=160257, qcols=qc, qscale=qs)
-        assert np.array_equal(b2, y2), (Ms, _diff_report(b2, y2))
-    assert L.clip_amd_test_gemm8p_launches() == n0 + 5
-
-
-def test_gemm8p_falls_back_outside_its_instantiations(L):
-    """Tile code 160257 with a residual epilogue, or a depth the persistent kernel is not instantiated for, runs on the 8-wave kernel of
-    k_gemm8.hip: same bits, launch counter untouched."""
-    rng = np.random.default_rng(3)
-    M, N = 900, 512
-    n0 = L.clip_amd_test_gemm8p_launches()
-    for K, epi in ((768, 4), (768, 0), (448, 1), (2048, 3)):
-        raw = ref.quantize(2, _weights(rng, N, K) * 3)
-        X = rng.standard_normal((M, K)).astype(np.float32)
-        bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
-        resid = rng.standard_normal((M, N)).astype(np.float32)
-        base = run_gemm(L, 2, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=128128)
-        assert np.array_equal(run_gemm(L, 2, raw, N, K, X, bias=bias, resid=resid, epi=epi, tile=160257), base), (K, epi)
-    assert L.clip_amd_test_gemm8p_launches() == n0
-
-
-@pytest.mark.parametrize("tname,h,N2,epi2", [("q4_0", 768, 2304, 1), ("q4_0", 768, 3072, 3), ("f16", 512, 2048, 3), ("q5_1", 1024, 3072, 2)])
-def test_gemm8p_consumes_a_folded_layernorm_bitwise_like_the_tiled_kernels(L, tname, h, N2, epi2):
-    """The persistent kernel as CONSUMER of a folded LayerNorm (q/k/v and FFN-up of a batch): row statistics reduced once per workgroup
-    for all of its tiles (LDS hand-off, then a register queue), rstd (acc - (mean - mu) c) + b' in the arithmetic half of the epilogue,
-    the row means left for the next producer by the first column tile.  Plain and centred fold: bit for bit the 160 x 128 consumer."""
-    rng = np.random.default_rng(h + N2)
-    M, K1 = 5000 + 11, 256                      # 32 x (N2 / 256) tiles of 160 x 256: 288 ... 384 on 256 workgroups
-    tid, raw1, raw2, Wd2, A, resid, b1, g, beta, b2 = _lnfold_case(rng, tname, M, h, K1, N2, mean_shift=2.0)
-    qc, qs = (h, 0.125) if epi2 == 1 else (0, 1.0)
-    for fold in (1, 2):
-        xa, ya = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, 160128, 160128, fold, qc, qs)
-        n0 = L.clip_amd_test_gemm8p_launches()
-        xb, yb = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, 160128, 160257, fold, qc, qs)
-        assert L.clip_amd_test_gemm8p_launches() == n0 + 1
-        assert np.array_equal(xa, xb)
-        assert np.all(np.isfinite(yb)) and np.array_equal(ya, yb), (fold, _diff_report(ya, yb))
-
-
 @pytest.mark.parametrize("seed", range(6))
 def test_large_m_kernels_random_shapes_bitwise(L, seed):
     """Seeded random (M, N, K): edges anywhere inside a 256 x 256 tile, 1 ... 11 K-tiles, random epilogue, bias present or not — the
