@@ -877,7 +877,7 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
     p.sk_ws = (float *)skw.p; p.sk_ws_floats = (size_t)16 << 20; p.sk_cnt = (unsigned *)skc.p; p.sk_cnt_n = 4096;
     DBuf panel((size_t)W.Npad * W.Kpad * 2);
     const bool pre = (epilogue >> 16) & 1;             // bit 16: time the GEMM alone on an already dequantised panel (per-layer form)
-    if (pre && W.wtype != W_F16 && panel.p) {
+    if (pre && W.wtype != W_F16 && W.wtype != W_F32 && panel.p) {
         const DevWeight * w = &W;
         half_t * o = (half_t *)panel.p;
         launch_dequant(&w, &o, 1, nullptr);
@@ -919,7 +919,7 @@ float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogu
         if (!repack_for_test(type, raw.data(), N, K, Wr, &base)) break;
         owned.push_back(base);
         const half_t * pr = nullptr;
-        if (pre && Wr.wtype != W_F16) {
+        if (pre && Wr.wtype != W_F16 && Wr.wtype != W_F32) {
             void * pp = nullptr;
             if (hipMalloc(&pp, (size_t)Wr.Npad * Wr.Kpad * 2) != hipSuccess) break;
             owned.push_back(pp);

@@ -110,6 +110,7 @@ double weight_bytes(const DevWeight & W) {
     case W_Q5_0: return nblk * 22;
     case W_Q5_1: return nblk * 24;
     case W_Q8_0: return nblk * 34;
+    case W_F32: return (double)W.N * W.K * 4;
     }
     return 0;
 }
@@ -130,7 +131,8 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
                       + (p.xg_out ? (double)p.M * p.W.N * 2 : 0.0);     // LayerNorm fold: the residual epilogue also writes the next GEMM's fp16 operand
     // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
-    if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
+    if (wt == W_F32) snprintf(fam, sizeof fam, "gemm_f32_kernel<%d>/%s", epi, what);      // f32 file: exact-f32 MFMA (k_gemm_f32.hip)
+    else if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
     else if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
     else if (gemm_tile_is_ring(tile)) snprintf(fam, sizeof fam, "gemm_ring_kernel<%d,%d,4,%d,%d>/%s", wt, tile % 1000, tile % 1000 >= 128 ? 4 : 2, epi, what);
     else snprintf(fam, sizeof fam, "gemm_dma_kernel<%d,%d,%d,%d>/%s", wt, gemm_tile_uses_panel(tile) ? 160 : tile / 1000, gemm_tile_uses_panel(tile) ? 128 : tile % 1000, epi, what);
@@ -165,7 +167,7 @@ LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows, const ha
     bool todo[4];
     for (int i = 0; i < 4; i++) {
         if (res && res[i]) { *slot[i] = res[i]; todo[i] = false; continue; }       // kept from the first large batch: nothing to dequantise
-        todo[i] = ws[i]->wtype != W_F16 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true));
+        todo[i] = ws[i]->wtype != W_F16 && ws[i]->wtype != W_F32 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true));
         if (todo[i]) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
     }
     if (!need || !ensure_panel(ctx, need)) return lp;
@@ -228,6 +230,7 @@ int skinny_row_limit() {     // rows up to which the small-M kernels carry the l
 bool layers_fit_skinny(const DevTower & tw, int rows, int h, int ff) {
     if (!skinny_enabled() || rows <= 0 || rows > skinny_row_limit() || h > 2048 || h % 16 || h / 16 > 128 || tw.layers.empty()) return false;
     const DevLayer & l = tw.layers[0];
+    if (l.qkv.wtype == W_F32 || l.o.wtype == W_F32 || l.ff1.wtype == W_F32 || l.ff2.wtype == W_F32) return false;   // f32 file: k_gemm_f32.hip carries every row count
     return l.qkv.K == l.qkv.Kpad && l.ff1.K == l.ff1.Kpad && l.o.N == h && l.ff2.N == h && l.ff1.N == ff;
 }
 
@@ -474,7 +477,7 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
     }
     const DevLayer & l0 = tw.layers[0];
     unsigned want = 0;
-    if (l0.ff2.wtype != W_F16 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
+    if (l0.ff2.wtype != W_F16 && l0.ff2.wtype != W_F32 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
     if (!want) return nullptr;
     auto & tab = ctx->res_panels[which];
     if ((ctx->res_panel_mask[which] & want) == want && tab.size() == 4 * tw.layers.size()) return tab.data();

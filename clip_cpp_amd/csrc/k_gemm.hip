@@ -539,6 +539,10 @@ int pick_ksplit_ring(int tiles, int nk, bool quantised) {
 
 void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stream) {
     if (p0.M <= 0) return;
+    if (p0.W.wtype == W_F32) {      // f32 GGUF file: f32 weights on the exact-f32 MFMA, whatever the tile code (k_gemm_f32.hip)
+        launch_gemm_f32(p0, epilogue, stream);
+        return;
+    }
     GemmParams p = p0;
     const bool heuristic = (tile == 0);
     int ksplit = tile / 1000000;        // explicit: ksplit * 1000000 + BM * 1000 + BN  (no prefix = no split)

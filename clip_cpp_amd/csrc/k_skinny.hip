@@ -392,7 +392,7 @@ void launch_skinny_wt5(const SkinnyParams &, int, hipStream_t);
 
 // which (epilogue, operand) combinations the skinny path covers; everything else stays on launch_gemm
 bool skinny_supported(const SkinnyParams & p, int epilogue) {
-    if (p.M <= 0 || p.M > SKINNY_MAX_ROWS || p.W.N % 4 || p.ldc % 4) return false;
+    if (p.M <= 0 || p.M > SKINNY_MAX_ROWS || p.W.N % 4 || p.ldc % 4 || p.W.wtype == W_F32) return false;   // (f32 weights: k_gemm_f32.hip)
     if (p.x32) {
         if (epilogue != EPI_F16 && epilogue != EPI_GELU_F16 && epilogue != EPI_QGELU_F16) return false;
         return p.W.K == p.W.Kpad && p.W.K <= 2048 && p.ldx % 4 == 0 && p.ln_w && p.ln_b && p.stats_in && p.stats_slots > 0;

@@ -30,10 +30,11 @@ inline void opt_in_dynamic_lds(K kernel, size_t bytes, unsigned long long & done
 }
 
 // Device weight formats (repacked from the ggml block layout at load time, see model.cpp).
-enum WType : int { W_F16 = 0, W_Q4_0 = 1, W_Q4_1 = 2, W_Q5_0 = 3, W_Q5_1 = 4, W_Q8_0 = 5 };
+enum WType : int { W_F16 = 0, W_Q4_0 = 1, W_Q4_1 = 2, W_Q5_0 = 3, W_Q5_1 = 4, W_Q8_0 = 5, W_F32 = 6 };
 
 // One linear weight W[N][K] (y = W x), resident in HBM in the GEMM-friendly layout:
 //   W_F16 : w16[Npad][Kpad] row-major fp16 (zero padded)
+//   W_F32 : the same matrix in f32 behind the same pointer (f32 GGUF files: multiplied on the exact-f32 MFMA, k_gemm_f32.hip)
 //   quant : "block-column-major" planes over nkb = Kpad/32 blocks of 32 weights:
 //           qs[kb][n]  16 B (q8_0: 32 B) of packed quants, nibble/byte order permuted for cheap unpack
 //           qh[kb][n]  4 B of fifth bits (q5_*), permuted
@@ -133,6 +134,8 @@ void launch_gemm_ring(const GemmParams & p, int epilogue, int bn, hipStream_t st
 
 // k_gemm8.hip: 8-wave ping-pong GEMM on (32 tm) x 256 tiles, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel), tm in {3,4,5}
 void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream);
+// k_gemm_f32.hip: every weight GEMM of an f32 file (W_F32: f32 weights x fp16 activations widened exactly, f32 MFMA); launch_gemm routes there
+void launch_gemm_f32(const GemmParams & p, int epilogue, hipStream_t stream);
 // k_gemm4.hip: 4 waves x (128 x 128) on 256 x 256 tiles, accumulators in AGPRs, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel)
 void launch_gemm4(const GemmParams & p, int epilogue, hipStream_t stream);
 // dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)

@@ -36,8 +36,14 @@ bool plan_repack(int type, int64_t N, int64_t K, RepackPlan & pl, std::string & 
     W.K = (int)K;
     W.Npad = (int)((N + 127) / 128 * 128);
     W.Kpad = (int)((K + 63) / 64 * 64);
-    if (type == GT_F32 || type == GT_F16) {
-        // f32 linear weights are rounded to fp16 once here (the MFMA path has fp16 operands)
+    if (type == GT_F32) {
+        // f32 files keep their linear weights in f32 (round 5; until then they were rounded to fp16 here — narrower than the reference's
+        // f32 vec_dot): multiplied on the exact-f32 MFMA by k_gemm_f32.hip
+        W.wtype = W_F32;
+        pl.bytes_w16 = (size_t)W.Npad * W.Kpad * 4;
+        return true;
+    }
+    if (type == GT_F16) {
         W.wtype = W_F16;
         pl.bytes_w16 = (size_t)W.Npad * W.Kpad * 2;
         return true;
@@ -62,17 +68,14 @@ bool plan_repack(int type, int64_t N, int64_t K, RepackPlan & pl, std::string & 
 void repack_rows(const RepackPlan & pl, int type, const uint8_t * src, int64_t N_each, int64_t K, int64_t row_off, uint8_t * qs_out,
                  uint8_t * qh_out, uint8_t * dm_out, uint8_t * w16_out) {
     const DevWeight & W = pl.W;
+    if (W.wtype == W_F32) {
+        float * dst = (float *)w16_out;
+        for (int64_t n = 0; n < N_each; n++) memcpy(dst + (row_off + n) * W.Kpad, src + (size_t)n * K * 4, (size_t)K * 4);
+        return;
+    }
     if (W.wtype == W_F16) {
         uint16_t * dst = (uint16_t *)w16_out;
-        for (int64_t n = 0; n < N_each; n++) {
-            uint16_t * drow = dst + (row_off + n) * W.Kpad;
-            if (type == GT_F16) {
-                memcpy(drow, src + (size_t)n * K * 2, (size_t)K * 2);
-            } else {
-                const float * s = (const float *)src + n * K;
-                for (int64_t k = 0; k < K; k++) drow[k] = f32_to_f16_bits(s[k]);
-            }
-        }
+        for (int64_t n = 0; n < N_each; n++) memcpy(dst + (row_off + n) * W.Kpad, src + (size_t)n * K * 2, (size_t)K * 2);
         return;
     }
     const int64_t nb_src = K / 32;
@@ -592,14 +595,16 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
     if (!ctx->weights_from_cache) cache.write_image(LL.st.buf);
     for (const Fix & f : LL.fixes) *f.slot = (const uint8_t *)ctx->weights_base + f.off;
     {   // LayerNorm fold vectors (k_fold.hip): computed on the device from the weights as the GEMM kernels dequantise them
+        bool f32_weights = false;                    // f32 file: weights stay f32 (k_gemm_f32.hip) — no fold, no small-M kernels, no panels for them
         for (DevTower * tw : {&ctx->vision, &ctx->text})
             for (DevLayer & l : tw->layers) {
+                if (l.qkv.wtype == W_F32 || l.o.wtype == W_F32 || l.ff1.wtype == W_F32 || l.ff2.wtype == W_F32) { f32_weights = true; continue; }
                 launch_fold_vectors(l.qkv, l.ln1_w, l.ln1_b, l.qkv_b, (float *)l.qkv_c, (float *)l.qkv_bf, ctx->stream);
                 launch_fold_vectors(l.ff1, l.ln2_w, l.ln2_b, l.ff1_b, (float *)l.ff1_c, (float *)l.ff1_bf, ctx->stream);
             }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) return fail("LayerNorm fold vectors: kernel failed");
         const char * e = getenv("CLIP_AMD_LNFOLD");
-        ctx->ln_fold = !(e && e[0] == '0');
+        ctx->ln_fold = !(e && e[0] == '0') && !f32_weights;
         ctx->ln_fold_force = e && e[0] == '2';       // tuning: fold even where forward.cpp fold_pays() says the LayerNorm launches are cheaper
         const char * e2 = getenv("CLIP_AMD_RESIDENT_PANELS");
         ctx->resident_panels_on = !(e2 && e2[0] == '0');

@@ -95,6 +95,32 @@ def test_gemm_all_weight_types_vs_dequant_reference(L, tname, shape):
     assert rel < (5e-4 if tname in ("f16", "f32") else 2e-2), rel
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (50, 768, 768), (257, 1024, 4096), (1600, 2304, 768), (333, 80, 192)])
+@pytest.mark.parametrize("epi", [0, 1, 3, 4])
+def test_f32_weights_are_multiplied_in_f32(L, M, N, K, epi):
+    """f32 GGUF weights (round 5, k_gemm_f32.hip): f32 weights x fp16 activations (widened exactly) on v_mfma_f32_16x16x4_f32, f32
+    accumulation — against the float64 product of the SAME operands the error is f32 rounding of the accumulation (~1e-6 of sum |x||w|), a
+    thousand times below what an fp16-rounded weight costs (2^-11); every epilogue family, edges inside the 64 x 64 tile."""
+    rng = np.random.default_rng(M + N + K + epi)
+    W = _weights(rng, N, K)
+    raw = ref.quantize(0, W)                                 # ggml type 0 = f32: the bytes of W
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if epi == 4 else None
+    y = run_gemm(L, 0, raw, N, K, X, bias=bias, resid=resid, epi=epi)
+    Xh = _h(X).astype(np.float64)
+    lin = Xh @ W.astype(np.float64).T + bias
+    mag = np.abs(Xh) @ np.abs(W.astype(np.float64)).T + np.abs(bias)
+    if epi == 0:
+        assert np.all(np.abs(y - lin) <= 2e-6 * mag + 1e-7), np.abs(y - lin).max()
+    elif epi == 4:
+        assert np.all(np.abs(y - (lin + resid)) <= 2e-6 * (mag + np.abs(resid)) + 1e-7)
+    else:
+        want = lin if epi == 1 else lin / (1.0 + np.exp(-1.702 * lin))
+        assert np.all(np.abs(y - want) <= np.abs(want) * 2.0 ** -10 + 2e-6 * mag + 1e-6), np.abs(y - want).max()   # the output's own fp16 rounding
+    assert np.array_equal(y, run_gemm(L, 0, raw, N, K, X, bias=bias, resid=resid, epi=epi))
+
+
 @pytest.mark.parametrize("tile", [64064, 64128, 128064, 128128, 160128, 192128, 96256, 128256, 160256, 256256, 256259])
 @pytest.mark.parametrize("tname", ["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_gemm_tiles_are_bitwise_identical(L, tile, tname):
