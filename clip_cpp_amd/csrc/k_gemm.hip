@@ -36,6 +36,8 @@
 // LDS->register->MFMA loop of this tile structure 1.5-1.8, tile streaming L2->LDS ~20 TB/s and not latency-bound.
 // The remaining step is a 256-wide register tile with a hand-scheduled (assembly) K loop.
 
+#include <vector>
+
 #include "gemm_common.h"
 
 namespace clipamd {
@@ -427,8 +429,29 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
 // one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
+// CLIP_AMD_TILE_OVERRIDE="M,N,tile[;M,N,tile...]" (tuning aid): the heuristic's answer for the listed problem sizes, so that a tile can be
+// A/B-ed INSIDE the layer chain (isolated GEMM timings over-state a tile's worth there: profiles/r05_experiments.txt section 3)
+int tile_override(int M, int N) {
+    struct Ov { int M, N, tile; };
+    static const std::vector<Ov> ovs = [] {
+        std::vector<Ov> v;
+        const char * e = getenv("CLIP_AMD_TILE_OVERRIDE");
+        while (e && *e) {
+            Ov o;
+            int used = 0;
+            if (sscanf(e, "%d,%d,%d%n", &o.M, &o.N, &o.tile, &used) == 3) v.push_back(o); else break;
+            e += used;
+            if (*e == ';') e++;
+        }
+        return v;
+    }();
+    for (const Ov & o : ovs) if (o.M == M && o.N == N) return o.tile;
+    return 0;
+}
+
 int pick_tile(int M, int N, int Kpad, bool quantised) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (const int ov = tile_override(M, N)) return ov;
     if (M <= 64) return 64064;
     // (round 5, measured and NOT done — profiles/r05_experiments.txt: the fp16-output GEMMs of the ViT-B/32 batch on resident fp16 panels and the
     //  four-wave 256 x 256 kernel — isolated q/k/v 57.3 us against 64.1, text q/k/v 25.7 against 29.4 — leave the vision q/k/v launch of the
@@ -477,7 +500,11 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
     for (int bm : cand) {
         const float x = (float)wgs(bm, 128) / 512.f;
         const float g = x <= 0.5f ? 0.7f : x <= 1.f ? 1.f : 0.75f * x + 0.25f * ceilf(x);
-        const float cost = g * (float)(bm + 32) * (bm == 64 ? 1.35f : 1.f);   // (1.15 until r03: the 4500-8000-row sweep has 128 x 128 ahead of 64 x 128 by 8-22 %)
+        // the constant = what a tile costs whatever its height (weight-tile dequantisation, prologue, epilogue latency): 32 rows' worth, 96 for
+        // short K (<= 12 K-tiles: the fixed part is a larger share of the tile).  r05, A/B INSIDE the two-tower step, five same-box pairs
+        // (profiles/r05/r05k_tile_override_ab2.txt): 192 x 128 for q/k/v of both towers 117.06 k against 115.65 k emb/s (+1.2 %, ranges disjoint)
+        const float fixed = Kpad / BK <= 12 ? 96.f : 32.f;
+        const float cost = g * ((float)bm + fixed) * (bm == 64 ? 1.35f : 1.f);   // (1.15 until r03: the 4500-8000-row sweep has 128 x 128 ahead of 64 x 128 by 8-22 %)
         if (best_cost == 0.f || cost < best_cost) { best_cost = cost; best = bm * 1000 + 128; }
     }
     return best;

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 TAG=${1:-r02}
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 if [ "${PROFILE_ONLY:-0}" != "1" ]; then
-echo "== GPU tests" ; timeout 1500 python -m pytest tests/ -m gpu -q 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" | tail -12 | tee gpurun_out/${TAG}_tests.log
+echo "== GPU tests" ; timeout 2400 python -m pytest tests/ -m gpu -q -p no:cacheprovider 2>&1 | grep -E " passed| failed| error|FAILED|ERROR|max .* mean|1-cos" | tail -24 | tee gpurun_out/${TAG}_tests.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/${TAG}_smoke.log
 echo "== bench" ; timeout 900 python bench.py --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -2 | cut -c1-4000 | tee gpurun_out/${TAG}_bench.log
 fi
