@@ -132,11 +132,26 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def weight_only_bytes(d, rep, dom):
+def kernel_grid_workgroups(name, shape):
+    """Workgroups of one launch of a tiled GEMM kernel at M x N x K — the key that separates the shapes of one instantiation in the per-grid
+    rocprofv3 files of scripts/gpu_round.sh.  None for kernels whose grid does not follow from the name alone (ring / small-M: split-K)."""
+    import re
+    M, N, K = (int(x) for x in shape.split("x"))
+    m = re.match(r"gemm_dma_kernel<\d+,(\d+),(\d+),\d+>", name)
+    if m and int(m.group(1)) > 64:
+        bm, bn = int(m.group(1)), int(m.group(2))
+        return -(-M // bm) * -(-N // bn)
+    m = re.match(r"gemm8_kernel<(\d+),\d+>", name)
+    if m:
+        return -(-M // (32 * int(m.group(1)))) * -(-N // 256)
+    return None
+
+
+def weight_only_bytes(d, rep, dom, shape=None):
     """weight bytes per launch of the dominant kernel instantiation: N x K x bits / 8 from its shapes (MxNxK tags) — the 8(d) byte count."""
     tot = n = 0
     for k, v in rep.items():
-        if k.split("/")[0] != dom:
+        if k.split("/")[0] != dom or (shape and k.split(":")[1] != shape):
             continue
         M, N, K = (int(x) for x in k.split(":")[1].split("x"))
         tot += v["launches"] * N * K * d.get("bits_per_weight", 4.5) / 8.0
@@ -643,18 +658,26 @@ def main():
         torch.cuda.synchronize()
         rep = clip.profile_report(reset=True)
         clip.profile(False)
-        # aggregate by kernel instantiation (= rocprofv3 kernel name), the roofline is quoted for the one with most time
-        inst = {}
+        # aggregate by kernel instantiation AND problem shape: the roofline is quoted for the (kernel, shape) with most time.  (Until round 4 the
+        # key was the instantiation alone = the rocprofv3 kernel name; since the q/k/v and FFN-up GEMMs of BOTH towers share one 192 x 128
+        # instantiation, a per-name average mixes a 12800 x 3072 x 768 launch with a 10290 x 2048 x 512 one.  scripts/gpu_round.sh therefore splits
+        # the rocprofv3 kernel trace and the PMC passes by grid size too — `roofline.grid_workgroups` is the key into those files — and the
+        # per-name view of the same instantiation stays in `roofline.instantiation_all_shapes`.)
+        inst, by_name = {}, {}
         for k, v in rep.items():
             if not (k.startswith("gemm") or k.startswith("skinny_kernel")):     # the weight-GEMM kernels (tiled, ring, small-M)
                 continue
-            name = k.split("/")[0]
-            a = inst.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, shapes=set()))
-            a["ms"] += v["ms"]; a["launches"] += v["launches"]; a["flops"] += v["flops"]; a["bytes"] += v["bytes"]
-            a["shapes"].add(k.split(":")[1])
+            name, shape = k.split("/")[0], k.split(":")[1]
+            for tab, key in ((inst, name + ":" + shape), (by_name, name)):
+                a = tab.setdefault(key, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, shapes=set(), name=name))
+                a["ms"] += v["ms"]; a["launches"] += v["launches"]; a["flops"] += v["flops"]; a["bytes"] += v["bytes"]
+                a["shapes"].add(shape)
         if inst:
-            dom = max(inst, key=lambda k: inst[k]["ms"])
-            d = inst[dom]
+            dom_key = max(inst, key=lambda k: inst[k]["ms"])
+            d = inst[dom_key]
+            dom = d["name"]
+            dom_shape = next(iter(d["shapes"]))
+            grid_wgs = kernel_grid_workgroups(dom, dom_shape)
             d["bits_per_weight"] = BITS_PER_WEIGHT[cfg["ftype"]]
             avg_ms = d["ms"] / d["launches"]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -670,7 +693,8 @@ def main():
                     elif args.config != tj.get("_config", "b32_q4_0_b256") or custom:
                         traffic_note = "pmc_traffic.json was measured on config %s" % tj.get("_config", "b32_q4_0_b256")
                     else:
-                        traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                        traffic = (tj.get("%s@%d" % (dom, grid_wgs)) if grid_wgs else None) or (tj.get(dom) if len(by_name[dom]["shapes"]) == 1 else None) or {}
+                        traffic = traffic.get("hbm_bytes_per_launch")
                         whole["traffic_bytes_per_step"] = tj.get("_whole_step_hbm_bytes")      # PMC sum over every launch of a step (tracked round over round)
                         if whole["traffic_bytes_per_step"]:
                             whole["traffic_over_algorithmic"] = round(whole["traffic_bytes_per_step"] / by_step, 1)
@@ -682,7 +706,7 @@ def main():
             # view is `roofline.frac`; the kernel-level HBM view — whose byte count also holds the activations, outputs and residual rows the
             # launch really moves — is kept under `other_bound` (until r03 `frac` was whichever view took longer).
             fl_l, by_l = d["flops"] / d["launches"], d["bytes"] / d["launches"]
-            wb_l = weight_only_bytes(d, rep, dom)
+            wb_l = weight_only_bytes(d, rep, dom, dom_shape)
             t_mfma, t_hbm_w = fl_l / (MFMA_F16_PEAK_TFLOPS * 1e12), wb_l / (HBM_PEAK_GBS * 1e9)
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             gbs_w = wb_l / (avg_ms * 1e-3) / 1e9
@@ -696,7 +720,13 @@ def main():
             roofline = dict(mfma_view if mfma_bound else hbm_w_view)
             other = hbm_k_view if mfma_bound else mfma_view
             roofline["frac_8d"] = roofline["frac"]          # (kept for readers of the r03 line: the same number)
-            roofline.update({"kernel": dom + " (fp16 MFMA weight GEMM; template args as in the rocprofv3 kernel name)",
+            n_all = by_name[dom]
+            roofline.update({"kernel": dom + " at " + dom_shape + " (M x N x K; fp16 MFMA weight GEMM; template args as in the rocprofv3 kernel name)",
+                             "grid_workgroups": grid_wgs,
+                             "instantiation_all_shapes": {"shapes_MxNxK": sorted(n_all["shapes"]), "launches": n_all["launches"],
+                                                          "avg_launch_us": round(n_all["ms"] / n_all["launches"] * 1e3, 2),
+                                                          "achieved_tflops": round(n_all["flops"] / (n_all["ms"] * 1e-3) / 1e12, 2),
+                                                          "note": "what a per-kernel-NAME average (rocprofv3 --stats) of this instantiation shows"},
                              "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
                              "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l, "weight_bytes_per_launch": wb_l,
                              "t_mfma_us": round(t_mfma * 1e6, 2), "t_hbm_us": round(t_hbm_w * 1e6, 2), "other_bound": other,

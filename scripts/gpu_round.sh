@@ -14,6 +14,24 @@ fi
 echo "== rocprof kernel trace (default config)" ; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python "$R/bench.py" --steps 10 --warmup 3 --preheat 0.3 --no-matrix --no-cpu-baseline --no-roofline --no-host-api > /tmp/prof_${TAG}.log 2>&1; tail -1 /tmp/prof_${TAG}.log | cut -c1-300)
 for f in $(find /tmp/prof_${TAG} -name "*kernel_stats*.csv"); do grep -v "at::native\|__amd_rocclr" $f | cut -c1-400 > gpurun_out/${TAG}_kernel_stats_b32_q4_0_b256.csv; done
 head -8 gpurun_out/${TAG}_kernel_stats_b32_q4_0_b256.csv | cut -c1-200
+# the same trace split by (kernel name, grid): one instantiation serves several GEMM shapes (both towers), a per-name average mixes them
+python - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("/tmp/prof_${TAG}/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "clipamd" not in k: continue
+        gx = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0); wx = int(r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or 1)
+        gy = int(r.get("Grid_Size_Y") or 1); wy = int(r.get("Workgroup_Size_Y") or 1)
+        acc[(k.replace("void clipamd::(anonymous namespace)::", "").split("(")[0], (gx // max(1, wx)) * max(1, gy // max(1, wy)))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+rows = sorted(((sum(v), k, v) for k, v in acc.items()), reverse=True)
+with open("gpurun_out/${TAG}_kernel_stats_by_grid_b32_q4_0_b256.csv", "w") as o:
+    o.write('"Name","Workgroups","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs"\n')
+    for tot, (name, wgs), v in rows:
+        o.write('"%s",%d,%d,%d,%.1f,%d,%d\n' % (name, wgs, len(v), tot, tot / len(v), min(v), max(v)))
+for tot, (name, wgs), v in rows[:10]: print("%-48s grid %5d WGs  x%5d  avg %8.1f us" % (name[:48], wgs, len(v), tot / len(v) / 1e3))
+PY
 echo "== rocprof kernel trace (batch 1, L/14 f16 batch 256)"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_b1 -o b1 -- python "$R/bench.py" --config b32_q4_0_b1 --vision-only --steps 50 --no-cpu-baseline --no-roofline --no-host-api > /tmp/prof_b1.log 2>&1)
 for f in $(find /tmp/prof_${TAG}_b1 -name "*kernel_stats*.csv"); do grep -v "at::native\|__amd_rocclr" $f | cut -c1-400 > gpurun_out/${TAG}_kernel_stats_b32_q4_0_b1.csv; done
@@ -36,6 +54,11 @@ for f in glob.glob("/tmp/pmc_${TAG}_*/**/*counter_collection.csv", recursive=Tru
         if "clipamd" not in k: continue
         k = k.replace("void clipamd::(anonymous namespace)::", "").split("(")[0].replace(" ", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+        try:      # ... and per (kernel name, workgroups of the dispatch): key "name@wgs" (bench.py roofline.grid_workgroups)
+            kg = "%s@%d" % (k, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+            acc[kg][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(kg, r["Counter_Name"])] += 1
+        except (KeyError, ValueError):
+            pass
 out = {}
 for k in acc:
     fs = acc[k].get("FETCH_SIZE", 0) / max(1, cnt[(k, "FETCH_SIZE")]); ws = acc[k].get("WRITE_SIZE", 0) / max(1, cnt[(k, "WRITE_SIZE")])
@@ -44,7 +67,7 @@ for k in acc:
     print("%-60s FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  -> HBM bytes/launch (fetch x2) %.3e  [%d launches]" % (k[:60], fs, ws, out[k]["hbm_bytes_per_launch"], cnt[(k, "FETCH_SIZE")]))
 import bench
 # whole step: every launch of the PMC run belongs to one of its (1 warm-up + 3 timed) steps (--no-rates --preheat 0), except the load-time fold_kernel
-tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items() if "fold_kernel" not in k)
+tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items() if "fold_kernel" not in k and "@" not in k)
 out["_whole_step_hbm_bytes"] = tot / 4.0
 print("whole step: %.3e HBM bytes (sum over every launch of a step; 4 steps in the PMC run)" % out["_whole_step_hbm_bytes"])
 out["_kernel_src_sha16"] = bench.kernel_source_sha16()      # bench.py reports roofline.traffic only while the kernel sources are these
