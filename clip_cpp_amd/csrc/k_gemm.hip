@@ -429,29 +429,29 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // not shrink with BM) and g() the wave quantisation: a lone workgroup per CU runs ~0.7x the time of a co-resident pair,
 // one partial round costs a full round, later rounds overlap (3/4 fractional + 1/4 ceil).  E.g. M = 12800, N = 768:
 // 600 tiles of 128x128 = 1.17 rounds, but 480 tiles of 160x128 = one round (measured 100.6 -> 79.8 us at K = 3072).
-// CLIP_AMD_TILE_OVERRIDE="M,N,tile[;M,N,tile...]" (tuning aid): the heuristic's answer for the listed problem sizes, so that a tile can be
-// A/B-ed INSIDE the layer chain (isolated GEMM timings over-state a tile's worth there: profiles/r05_experiments.txt section 3)
-int tile_override(int M, int N) {
-    struct Ov { int M, N, tile; };
+// CLIP_AMD_TILE_OVERRIDE="M,N,K,tile[;M,N,K,tile...]" (tuning aid; K = 0 matches any depth): the heuristic's answer for the listed problem
+// sizes, so that a tile can be A/B-ed INSIDE the layer chain (isolated GEMM timings over-state a tile's worth there: profiles/r05_experiments.txt section 3)
+int tile_override(int M, int N, int Kpad) {
+    struct Ov { int M, N, K, tile; };
     static const std::vector<Ov> ovs = [] {
         std::vector<Ov> v;
         const char * e = getenv("CLIP_AMD_TILE_OVERRIDE");
         while (e && *e) {
             Ov o;
             int used = 0;
-            if (sscanf(e, "%d,%d,%d%n", &o.M, &o.N, &o.tile, &used) == 3) v.push_back(o); else break;
+            if (sscanf(e, "%d,%d,%d,%d%n", &o.M, &o.N, &o.K, &o.tile, &used) == 4) v.push_back(o); else break;
             e += used;
             if (*e == ';') e++;
         }
         return v;
     }();
-    for (const Ov & o : ovs) if (o.M == M && o.N == N) return o.tile;
+    for (const Ov & o : ovs) if (o.M == M && o.N == N && (o.K == 0 || o.K == Kpad)) return o.tile;
     return 0;
 }
 
 int pick_tile(int M, int N, int Kpad, bool quantised) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (const int ov = tile_override(M, N)) return ov;
+    if (const int ov = tile_override(M, N, Kpad)) return ov;
     if (M <= 64) return 64064;
     // (round 5, measured and NOT done — profiles/r05_experiments.txt: the fp16-output GEMMs of the ViT-B/32 batch on resident fp16 panels and the
     //  four-wave 256 x 256 kernel — isolated q/k/v 57.3 us against 64.1, text q/k/v 25.7 against 29.4 — leave the vision q/k/v launch of the
