@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
 #undef ISSUE_W
 
     const int nb = n0 + wn * 64, mb = m0 + wm * TM * 16;
+    // the lane coordinates are derived again for the epilogue (v_mbcnt, opaque to CSE): the 256 x 256 tile's residual + fold epilogue is at
+    // the register limit, and a value kept across the K loop only for the epilogue's sake was spilled to scratch (12 bytes, r04 table)
+    unsigned lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int frow_e = (int)(lane_e & 15u), fgrp_e = (int)(lane_e >> 4), lane_i = (int)lane_e;
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) stamp[2] = __builtin_amdgcn_s_memtime();
 #endif
@@ -275,16 +280,16 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
     if constexpr (LNE) {
         if (ln) ln_rows_publish(ln_rs, ln_mine, tid, BM, [] { __syncthreads(); });
     }
-    const float2 * rs_lane = ln_rs + wm * TM * 16 + frow;
+    const float2 * rs_lane = ln_rs + wm * TM * 16 + frow_e;
     half_t * stage = (half_t *)smem + wave * (TM * 16) * 68;
     bool done = false;
     if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
         if (nb + 64 <= p.W.N && (p.ldc & 7) == 0) {    // uniform per wave
-            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, stage, lane, ln, rs_lane);
+            gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow_e, fgrp_e, stage, lane_i, ln, rs_lane);
             done = true;
         }
     }
-    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow, fgrp, ln, rs_lane, stage, lane);
+    if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow_e, fgrp_e, ln, rs_lane, stage, lane_i);
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
         stamp[3] = __builtin_amdgcn_s_memtime();       // stores issued (not necessarily landed)
