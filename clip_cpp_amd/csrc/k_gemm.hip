@@ -623,11 +623,10 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
-            if (tile % 1000 == 259 && !p.xg_out) {      // (consumer half of the LayerNorm fold: in the kernel since round 5)
+            if (tile % 1000 == 259) {      // (both halves of the LayerNorm fold since round 5: consumer in the fp16 epilogues, producer by re-reading the stored rows)
                 launch_gemm4(p, epilogue, stream);
                 return;
             }
-            if (tile % 1000 == 259) tile = 256256;     // LayerNorm-folded launch: the four-wave kernel carries no fold code (r04: built in halves of a wave's columns, the residual + fold epilogue still spilled 196 registers beside the 256 AGPR accumulators and cost +80 ... +125 us per launch, and its mere presence slowed the unfolded path by 10-30 %: profiles/r04_experiments.txt), the 8-wave 256 x 256 tile does
             launch_gemm8(p, epilogue, tile / 32000, stream);
             return;
         }

@@ -170,12 +170,6 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     constexpr bool LNE = EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16;
     float2 * const ln_rs = (float2 *)(smem + 2 * STAGE);
     const bool ln = LNE && p.ln_c != nullptr;
-    if constexpr (LNE) {
-        if (ln) {
-            ln_rs[tid] = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, n0 == 0 && m0 + tid < p.M);
-            __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0), as a builtin: hipcc's own counting restarts from zero
-        }
-    }
     f4 acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; a++)
@@ -197,12 +191,15 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
 #endif
     // prologue: tiles 0 and 1 requested, tile 0 awaited, its first k-slice read
     G4_ISSUE(0, 0);
-    if (T > 1) {
-        G4_ISSUE(STAGE, 1);
-        wait_vmcnt4<2 * NR>();
-    } else {
-        wait_vmcnt4<0>();
+    if (T > 1) G4_ISSUE(STAGE, 1);
+    if constexpr (LNE) {
+        // the statistics round trip runs under the landing of the first K-tiles (in front of the requests it cost every tile ~1 us of nothing)
+        if (ln) {
+            ln_rs[tid] = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, n0 == 0 && m0 + tid < p.M);
+            __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0), as a builtin: hipcc's own counting restarts from zero (both K-tiles have landed too)
+        }
     }
+    if (T > 1) wait_vmcnt4<2 * NR>(); else wait_vmcnt4<0>();
     raw_barrier4();
     G4_READ(w0, x0, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the loop is entered with nothing pending (counted waits inside)
@@ -270,6 +267,16 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     if (!done) {
         if constexpr (LNE) gemm_epilogue<EPI, TN, TM, true>(p, acc, nb, mb, frow_e, fgrp_e, ln, rs_lane);
         else gemm_epilogue<EPI, TN, TM, false>(p, acc, nb, mb, frow_e, fgrp_e, false, nullptr);
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+        // PRODUCER half of the LayerNorm fold (round 5): the accumulators leave no registers for the in-register tail, so the tile's new rows are
+        // re-read from L2 once the epilogue's stores are out — a wave takes 64 rows, one coalesced row per iteration (gemm_common.h resid_fold_tail_reread256)
+        if (p.xg_out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            resid_fold_tail_reread256(p, m0, n0, wave, lane_i);
+        }
     }
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
