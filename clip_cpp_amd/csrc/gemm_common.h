@@ -354,67 +354,6 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
     }
 }
 
-// The same producer half for a kernel that has no registers left beside its accumulators (k_gemm4.hip: 256 of them per lane; the in-register
-// tail above spilled 196 there): AFTER the residual epilogue has stored the tile's new f32 rows, each wave re-reads ROWS of the tile from L2 (the
-// lines were written by this very CU a moment ago) — one row per iteration, lane l <-> columns 4 l ... 4 l + 3 of the 256-column tile, so a row is ONE
-// coalesced 1 KB load and its xg ONE coalesced 512-byte store — and produces the row's statistics slots and xg columns.  (A first form — thread t
-// takes row t — cost 25-35 us per tile: 64 cache lines per load instruction.)  Same values (the stored f32 rows ARE the accumulators of the
-// in-register form), same summation trees: a 32-column unit = 8 lanes = strips A (lanes g) and B (lanes 4 + g) of the MFMA layout's "fgrp lanes";
-// p_g = sum4(A_g) + sum4(B_g) (exchange with lane ^ 4), then (p_g + p_{g^1}) + (p_{g^2} + p_{g^3}) (lane ^ 1, lane ^ 2: sum4_fgrp's butterfly), two
-// passes; the 64-column slot = ln_pair32 of its two units (lane ^ 8) — the bits do not depend on which form produced them (tests).
-// Cross-lane moves: DPP quad_perm / row_ror on the VALU for ^1, ^2, ^8, ds_swizzle for ^4.  Call behind a workgroup-scope release / barrier / acquire.
-template <int CTRL> __device__ __forceinline__ float dpp_movf(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float lane_xor4f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F)); }   // BitMode: and 0x1F, or 0, xor 4
-
-__device__ __forceinline__ void resid_fold_tail_reread256(const GemmParams & p, int mbase, int nbase, int wave, int lane) {
-    constexpr int XOR1 = 0xB1, XOR2 = 0x4E, ROR8 = 0x128;      // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:8 (= lane ^ 8 inside a row of 16)
-    const int N = p.W.N;
-    const int n = nbase + 4 * lane;
-    const bool cols = n < N;                                   // (N is a multiple of 64 on this path: a lane's 4 columns are inside or outside together)
-    const int nc = cols ? n : N - 4;                           // lanes past N compute on clamped columns and store nothing
-    const f4 gam = *(const f4 *)(p.xg_gamma + nc);
-    const int m_first = mbase + 64 * wave;
-    auto sum4 = [](const f4 & a) { return (a[0] + a[1]) + (a[2] + a[3]); };
-    auto sq4 = [](const f4 & a) { return (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]); };
-    constexpr int RB = 4;                                      // rows in flight per wave
-    for (int r0 = 0; r0 < 64; r0 += RB) {
-        if (m_first + r0 >= p.M) break;                        // (uniform)
-        f4 x[RB];
-        float mu[RB];
-#pragma unroll
-        for (int j = 0; j < RB; j++) {
-            const int m = m_first + r0 + j < p.M ? m_first + r0 + j : p.M - 1;
-            x[j] = *(const f4 *)((const float *)p.out + (size_t)m * p.ldc + nc);
-            mu[j] = p.xg_mu ? p.xg_mu[m] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; j++) {
-            const int m = m_first + r0 + j;
-            const float a = sum4(x[j]);
-            const float pg = a + lane_xor4f(a);
-            const float s1 = pg + dpp_movf<XOR1>(pg);
-            const float s = s1 + dpp_movf<XOR2>(s1);           // sum of the unit's 32 columns, in every one of its 8 lanes
-            const float mean = s * (1.0f / 32.0f);
-            const float b = sq4(x[j] - mean);
-            const float pq = b + lane_xor4f(b);
-            const float q1 = pq + dpp_movf<XOR1>(pq);
-            const float q = q1 + dpp_movf<XOR2>(q1);
-            const float so = dpp_movf<ROR8>(s), qo = dpp_movf<ROR8>(q);      // the other unit of this 64-column slot
-            const bool upper = (lane & 8) != 0;
-            float mean64, q64;
-            ln_pair32(upper ? so : s, upper ? qo : q, upper ? s : so, upper ? q : qo, mean64, q64);
-            if (m < p.M && cols) {
-                if ((lane & 15) == 0) p.stats_out[(size_t)(n / 64) * p.stats_stride + m] = make_float2(mean64 * 64.f, q64);
-                const f4 g = (x[j] - mu[j]) * gam;
-                const h2 lo = (h2){(_Float16)g[0], (_Float16)g[1]}, hi = (h2){(_Float16)g[2], (_Float16)g[3]};
-                *(uint2 *)(p.xg_out + (size_t)m * p.ldxg + n) = make_uint2(h2u(lo), h2u(hi));
-            }
-        }
-    }
-}
-
 // consumer half: v = acc + bias, or with the fold rstd_m (acc - mean_m c_n) + b'_n
 __device__ __forceinline__ f4 ln_apply(bool ln, const float2 & mr, const f4 & acc, const f4 & c, const f4 & bias) {
     if (ln) return (acc - c * mr.x) * mr.y + bias;

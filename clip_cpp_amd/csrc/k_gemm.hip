@@ -623,10 +623,11 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
-            if (tile % 1000 == 259) {      // (both halves of the LayerNorm fold since round 5: consumer in the fp16 epilogues, producer by re-reading the stored rows)
+            if (tile % 1000 == 259 && !p.xg_out) {      // (consumer half of the LayerNorm fold: in the kernel since round 5)
                 launch_gemm4(p, epilogue, stream);
                 return;
             }
+            if (tile % 1000 == 259) tile = 256256;     // fold PRODUCER launch: the 8-wave 256 x 256 tile carries the in-register tail (k_gemm4.hip says why it does not)
             launch_gemm8(p, epilogue, tile / 32000, stream);
             return;
         }

@@ -250,8 +250,10 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     unsigned lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const int frow_e = (int)(lane_e & 15u), fgrp_e = (int)(lane_e >> 4), lane_i = (int)lane_e;
-    // (LayerNorm fold: the consumer half only — rs_lane: this lane's rows of the pairs parked in the prologue; the producer half of the
-    //  residual epilogue is compiled out, FOLD = false there: launch_gemm sends producer launches to the 8-wave 256 x 256 tile)
+    // (LayerNorm fold: the consumer half only — rs_lane: this lane's rows of the pairs parked in the prologue.  The producer half stays out of this
+    //  kernel, launch_gemm sends producer launches to the 8-wave 256 x 256 tile: in registers it spills 196 beside the accumulators (r04), and re-reading
+    //  the stored rows — round 5, commit in profiles/r05_experiments.txt section 11, bit-identical — costs 130-160 us per launch: a workgroup that has its
+    //  CU to itself must first wait out the drain of its own 256 KB of stores, which otherwise hides under the next tile's prologue)
     const float2 * rs_lane = ln_rs + wm * 128 + frow_e;
     bool done = false;
     if constexpr (LNE) {
@@ -267,16 +269,6 @@ __global__ void __launch_bounds__(NT4, 1) gemm4_kernel(const GemmParams p) {
     if (!done) {
         if constexpr (LNE) gemm_epilogue<EPI, TN, TM, true>(p, acc, nb, mb, frow_e, fgrp_e, ln, rs_lane);
         else gemm_epilogue<EPI, TN, TM, false>(p, acc, nb, mb, frow_e, fgrp_e, false, nullptr);
-    }
-    if constexpr (EPI == EPI_RESID_F32) {
-        // PRODUCER half of the LayerNorm fold (round 5): the accumulators leave no registers for the in-register tail, so the tile's new rows are
-        // re-read from L2 once the epilogue's stores are out — a wave takes 64 rows, one coalesced row per iteration (gemm_common.h resid_fold_tail_reread256)
-        if (p.xg_out) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            resid_fold_tail_reread256(p, m0, n0, wave, lane_i);
-        }
     }
 #ifdef CLIPAMD_G8_TIMING
     if (stamper) {
