@@ -22,6 +22,8 @@
 // T <= 288 for every d_head in {32,64,80,88,96,104} (all 224-px models and every text length); T <= 592 for d_head <= 64
 // (ViT-L/14 at 336 px: T = 577, 154.6 KB of LDS); longer sequences are rejected by the launcher.
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace clipamd {
@@ -33,7 +35,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifdef CLIPAMD_ATTN_ABL
+#define ATTN_ABL(x_) (x_)
+#else
+#define ATTN_ABL(x_) false
+#endif
+
 struct AttnParams {
+    int debug = 0;        // -DCLIPAMD_ATTN_ABL tuning builds (CLIP_AMD_ATTN_DEBUG): 1 no K / V staging loads, 2 no query blocks (staging only), 4 no output stores
     const half_t * qkv;   // [rows][3h]
     half_t * out;         // [rows][h]
     const int * seq_start;
@@ -50,6 +59,7 @@ struct AttnTile {
     const half_t * Qg;
     half_t * Og;          // output rows of this sequence, already offset to the head's columns
     int ld, h, len, causal, fq, fg;
+    bool nostore = false;
 };
 
 // QB consecutive 16-query blocks starting at block qb0 (blocks beyond the sequence are computed on clamped rows and not stored).
@@ -182,7 +192,7 @@ __device__ __forceinline__ void attn_blocks(const AttnTile<NT, DKS, DT> & t, int
                 half_t * orow = t.Og + (size_t)q * t.h + fq;
 #pragma unroll
                 for (int dt = 0; dt < DT; dt++)
-                    if (DHR == DT * 16 || dt * 16 + fq < DHR) orow[dt * 16] = (_Float16)(o[j][dt][r] * invr[r]);
+                    if ((DHR == DT * 16 || dt * 16 + fq < DHR) && !ATTN_ABL(t.nostore)) orow[dt * 16] = (_Float16)(o[j][dt][r] * invr[r]);
             }
         }
     }
@@ -240,15 +250,15 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
             const int it = tid + i * 256;
             const int key = it / KCH, c = it % KCH;
             const int kc = key < len ? key : len - 1, cc = c < DCH ? c : DCH - 1;
-            kv[i] = *(const u32x4 *)(Kg + (size_t)kc * ld + cc * 8);
+            kv[i] = ATTN_ABL(p.debug & 1) ? (u32x4){0u, 0u, 0u, 0u} : *(const u32x4 *)(Kg + (size_t)kc * ld + cc * 8);
         }
 #pragma unroll
         for (int i = 0; i < VIT; i++) {
             const int it = tid + i * 256;
             const int kp = it % NPAIR, c = (it / NPAIR) < DCH ? (it / NPAIR) : DCH - 1;
             const int k0 = 2 * kp;
-            va[i] = *(const u32x4 *)(Vg + (size_t)(k0 < len ? k0 : len - 1) * ld + c * 8);
-            vb[i] = *(const u32x4 *)(Vg + (size_t)(k0 + 1 < len ? k0 + 1 : len - 1) * ld + c * 8);
+            va[i] = ATTN_ABL(p.debug & 1) ? (u32x4){0u, 0u, 0u, 0u} : *(const u32x4 *)(Vg + (size_t)(k0 < len ? k0 : len - 1) * ld + c * 8);
+            vb[i] = ATTN_ABL(p.debug & 1) ? (u32x4){0u, 0u, 0u, 0u} : *(const u32x4 *)(Vg + (size_t)(k0 + 1 < len ? k0 + 1 : len - 1) * ld + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < KIT; i++) {
@@ -283,12 +293,12 @@ __global__ void __launch_bounds__(256, (NT > 18 ? 1 : NT <= 5 ? 4 : 2)) attn_ker
     __syncthreads();
 
     const int fq = lane & 15, fg = lane >> 4;
-    const int nqb = (len + 15) >> 4;
+    const int nqb = ATTN_ABL(p.debug & 2) ? 0 : (len + 15) >> 4;
 
     // Query blocks are processed in PAIRS where the register budget allows (QB = 2: every K / V^T fragment read from LDS
     // feeds two MFMAs, halving the LDS traffic that bounds this kernel at T = 257), the odd last block alone.
     constexpr int QB = (NT >= 7 && NT <= 18 && DT <= 6) ? 2 : 1;      // (d_head 104: 7 output tiles + 4 k-steps do not leave registers for block pairs)
-    const AttnTile<NT, DKS, DT> t{Ks, Vt, Qg, p.out + (size_t)row0 * p.h + head * DH, ld, p.h, len, p.causal, fq, fg};
+    const AttnTile<NT, DKS, DT> t{Ks, Vt, Qg, p.out + (size_t)row0 * p.h + head * DH, ld, p.h, len, p.causal, fq, fg, (p.debug & 4) != 0};
     // gridDim.y workgroups share one (sequence, head): each stages K / V^T itself and takes every gridDim.y-th set of four work units
     // (few sequences x heads and many query blocks — one ViT-L/14 image is 16 workgroups of 17 query blocks otherwise)
     const int slot = wave + 4 * blockIdx.y, nslot = 4 * gridDim.y;
@@ -360,6 +370,9 @@ bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform,
     p.h = h;
     p.n_head = n_head;
     p.causal = causal ? 1 : 0;
+#ifdef CLIPAMD_ATTN_ABL
+    { const char * e = getenv("CLIP_AMD_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
+#endif
     const int nt = (max_len + 15) / 16;
     switch (dh) {
     case 32: return launch_nt<1, 2>(p, nseq, nt, stream);
