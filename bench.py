@@ -729,7 +729,7 @@ def main():
                                                           "note": "what a per-kernel-NAME average (rocprofv3 --stats) of this instantiation shows"},
                              "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
                              "algorithmic_flops_per_launch": fl_l, "algorithmic_bytes_per_launch": by_l, "weight_bytes_per_launch": wb_l,
-                             "t_mfma_us": round(t_mfma * 1e6, 2), "t_hbm_us": round(t_hbm_w * 1e6, 2), "other_bound": other,
+                             "t_mfma_us": round(t_mfma * 1e6, 5), "t_hbm_us": round(t_hbm_w * 1e6, 5), "other_bound": other,
                              "shapes_MxNxK": sorted(d["shapes"]), "share_of_kernel_time": round(d["ms"] / total_ms, 3)})
             kernels = {k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] else None}
