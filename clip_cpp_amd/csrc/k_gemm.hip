@@ -494,17 +494,18 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
         // the 8-wave kernel gains there, r02h), so they take this path only where a layer is milliseconds long
         if (t8 >= 200 && eff >= 0.75f && (M >= 32768 || (Kpad >= 2048 && !quantised))) return 160256;
     }
+    // One exception measured INSIDE the two-tower step (r05, profiles/r05_experiments.txt section 9): the q/k/v GEMM of a narrow tower (10290 x 1536 x 512, the
+    // ViT-B/32 text tower of the BASELINE batch) on 192 x 128 instead of the model's 128 x 128: +1.0 % of the step in five same-box pairs — level in
+    // isolation (33.4 vs 32.8 us): fewer, larger workgroups leave the other tower's kernels more room.  (A larger fixed part in the cost model, which also
+    // moves the wide tower's q/k/v and FFN-up to 192 x 128, gains another 0.2 % there and LOSES 1-3 % at 96 / 176 / 224 / 400 / 512 images: section 9. Not kept.)
+    if (Kpad <= 512 && N <= 1536 && N >= 1024 && M >= 8192 && M <= 16384) return 192128;
     int best = 128128;
     float best_cost = 0.f;
     const int cand[4] = {128, 160, 192, 64};
     for (int bm : cand) {
         const float x = (float)wgs(bm, 128) / 512.f;
         const float g = x <= 0.5f ? 0.7f : x <= 1.f ? 1.f : 0.75f * x + 0.25f * ceilf(x);
-        // the constant = what a tile costs whatever its height (weight-tile dequantisation, prologue, epilogue latency): 32 rows' worth, 96 for
-        // short K (<= 12 K-tiles: the fixed part is a larger share of the tile).  r05, A/B INSIDE the two-tower step, five same-box pairs
-        // (profiles/r05/r05k_tile_override_ab2.txt): 192 x 128 for q/k/v of both towers 117.06 k against 115.65 k emb/s (+1.2 %, ranges disjoint)
-        const float fixed = Kpad / BK <= 12 ? 96.f : 32.f;
-        const float cost = g * ((float)bm + fixed) * (bm == 64 ? 1.35f : 1.f);   // (1.15 until r03: the 4500-8000-row sweep has 128 x 128 ahead of 64 x 128 by 8-22 %)
+        const float cost = g * (float)(bm + 32) * (bm == 64 ? 1.35f : 1.f);   // (1.15 until r03: the 4500-8000-row sweep has 128 x 128 ahead of 64 x 128 by 8-22 %)
         if (best_cost == 0.f || cost < best_cost) { best_cost = cost; best = bm * 1000 + 128; }
     }
     return best;
