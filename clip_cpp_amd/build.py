@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "libclip.so")
 GGML_STUB = os.path.join(HERE, "libggml.so")
 ARCH = "gfx950"
 
-HOST_SOURCES = ["gguf.cpp", "quant.cpp", "load.cpp", "forward.cpp", "tokenizer.cpp", "preprocess.cpp", "image_io.cpp",
+HOST_SOURCES = ["gguf.cpp", "quant.cpp", "load.cpp", "forward.cpp", "tokenizer.cpp", "preprocess.cpp", "image_io.cpp", "image_formats.cpp",
                 "jpeg_decode.cpp", "host_pipeline.cpp", "api.cpp"]
 HIP_SOURCES = ["k_attn.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip", "k_gemm4.hip", "k_gemm_f32.hip", "k_skinny.hip", "k_gemm_ring.hip", "k_fold.hip"]
 GEMM_WTYPES = [0, 1, 2, 3, 4, 5]

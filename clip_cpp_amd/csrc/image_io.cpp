@@ -1,8 +1,8 @@
 // image_io.cpp — clip_image_load_from_file (reference clip.cpp:709-726, which delegates to the vendored
 // stb_image).  Host-side and outside the GPU hot path.  Own decoders, 3-channel RGB
-// output like stbi_load(..., 3): binary PNM (P5/P6), uncompressed 24/32-bit BMP, PNG (8/16-bit, all
-// colour types, non-interlaced and Adam7, inflate via zlib) and JPEG (jpeg_decode.cpp: baseline +
-// progressive Huffman).
+// output like stbi_load(..., 3): PNG here (8/16-bit, all colour types, non-interlaced and Adam7, inflate
+// via zlib), JPEG in jpeg_decode.cpp (baseline + progressive Huffman, grey / YCbCr / RGB / CMYK / YCCK),
+// BMP / GIF / PSD / PNM / TGA in image_formats.cpp.  Formats are tried in the reference decoder's order.
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -16,6 +16,12 @@
 namespace clipamd {
 
 bool decode_jpeg(const uint8_t * data, size_t size, std::vector<uint8_t> & rgb, int & nx, int & ny, std::string & err);  // jpeg_decode.cpp
+// image_formats.cpp
+bool decode_bmp(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
+bool decode_gif(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
+bool decode_psd(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
+bool decode_pnm(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
+bool decode_tga(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
 
 namespace {
 
@@ -30,61 +36,6 @@ bool read_file(const char * fname, std::vector<uint8_t> & out) {
     const bool ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n;
     fclose(f);
     return ok;
-}
-
-// ---- PNM ----
-bool decode_pnm(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
-    if (d.size() < 7 || d[0] != 'P' || (d[1] != '5' && d[1] != '6')) return false;
-    const int ch = d[1] == '6' ? 3 : 1;
-    size_t p = 2;
-    int vals[3], got = 0;
-    while (got < 3 && p < d.size()) {
-        if (d[p] == '#') { while (p < d.size() && d[p] != '\n') p++; continue; }
-        if (d[p] == ' ' || d[p] == '\t' || d[p] == '\n' || d[p] == '\r') { p++; continue; }
-        int v = 0, nd = 0;
-        while (p < d.size() && d[p] >= '0' && d[p] <= '9') {
-            if (v > 100000000) return false;           // absurd header value: no signed overflow on long digit runs
-            v = v * 10 + (d[p] - '0'); p++; nd++;
-        }
-        if (!nd) return false;
-        vals[got++] = v;
-    }
-    if (got < 3 || p >= d.size()) return false;
-    p++;  // single whitespace after maxval
-    nx = vals[0]; ny = vals[1];
-    if (nx <= 0 || ny <= 0 || vals[2] != 255 || (size_t)nx * (size_t)ny > ((size_t)1 << 28)) return false;
-    const size_t need = (size_t)nx * ny * ch;
-    if (d.size() - p < need) return false;
-    rgb.resize((size_t)nx * ny * 3);
-    for (size_t i = 0; i < (size_t)nx * ny; i++)
-        for (int c = 0; c < 3; c++) rgb[i * 3 + c] = d[p + i * ch + (ch == 3 ? c : 0)];
-    return true;
-}
-
-// ---- BMP (BITMAPINFOHEADER, BI_RGB, 24/32 bpp) ----
-bool decode_bmp(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
-    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
-    auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, &d[o], 4); return v; };
-    auto i32 = [&](size_t o) { int32_t v; memcpy(&v, &d[o], 4); return v; };
-    auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, &d[o], 2); return v; };
-    const uint32_t off = u32(10);
-    const int w = i32(18), hh = i32(22), bpp = u16(28);
-    if (u32(30) != 0 || (bpp != 24 && bpp != 32) || w <= 0 || hh == 0 || hh == INT32_MIN) return false;
-    const int h = hh < 0 ? -hh : hh;
-    if ((size_t)w * (size_t)h > ((size_t)1 << 28)) return false;
-    const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
-    if (d.size() < off + stride * h) return false;
-    nx = w; ny = h;
-    rgb.resize((size_t)w * h * 3);
-    for (int y = 0; y < h; y++) {
-        const uint8_t * row = &d[off + stride * (hh < 0 ? y : h - 1 - y)];
-        for (int x = 0; x < w; x++) {
-            const uint8_t * px = row + (size_t)x * (bpp / 8);
-            uint8_t * o = &rgb[((size_t)y * w + x) * 3];
-            o[0] = px[2]; o[1] = px[1]; o[2] = px[0];
-        }
-    }
-    return true;
 }
 
 // ---- PNG ----
@@ -220,8 +171,9 @@ bool load_image_file(const char * fname, clip_image_u8 * img) {
     std::string err;
     bool ok = read_file(fname, d);
     if (ok) {
-        ok = decode_pnm(d, rgb, nx, ny) || decode_bmp(d, rgb, nx, ny) || decode_png(d, rgb, nx, ny) ||
-             decode_jpeg(d.data(), d.size(), rgb, nx, ny, err);
+        // (the order of the reference's decoder: formats with a magic number first, TGA — which has none — last)
+        ok = decode_png(d, rgb, nx, ny) || decode_bmp(d, rgb, nx, ny) || decode_gif(d, rgb, nx, ny) || decode_psd(d, rgb, nx, ny) ||
+             decode_jpeg(d.data(), d.size(), rgb, nx, ny, err) || decode_pnm(d, rgb, nx, ny) || decode_tga(d, rgb, nx, ny);
     }
     if (!ok) {
         fprintf(stderr, "%s: failed to load '%s'%s%s\n", "clip_image_load_from_file", fname, err.empty() ? "" : ": ", err.c_str());

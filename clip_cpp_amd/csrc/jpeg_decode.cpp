@@ -8,7 +8,7 @@
 //   * integer "slow" IDCT of Loeffler/Ligtenberg/Moschytz with 12-bit constants, two passes (>>10, >>17),
 //   * chroma up-sampling: 2x horizontal / vertical / both with the 3:1 "triangle" filter, nearest for other factors,
 //   * YCbCr -> RGB in 20-bit fixed point (1.40200, 0.34414 (truncated to 16 bits), 0.71414, 1.77200),
-//   * grey-scale -> RGB replication.  CMYK / Adobe-transform (4-component) files are rejected.
+//   * grey-scale -> RGB replication; four-component files: CMYK / YCCK per the Adobe APP14 transform (else YCbCr + ignored channel).
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -90,8 +90,9 @@ struct Decoder {
     uint16_t qt[4][64];
     Huff hdc[4], hac[4];
     int restart_interval = 0;
-    bool saw_adobe = false;
-    int adobe_transform = -1;
+    bool saw_adobe = false, saw_jfif = false;
+    int adobe_transform = -1;   // APP14 colour transform: 0 = samples stored as they are (RGB / CMYK), 1 = YCbCr, 2 = YCCK
+    int rgb_ids = 0;            // components whose id spells 'R', 'G', 'B' in that order
 
     // bit reader
     uint32_t bitbuf = 0;
@@ -381,13 +382,15 @@ struct Decoder {
         width = get16();
         ncomp = get8();
         if (height <= 0 || width <= 0) return fail("bad image size");
-        if (ncomp != 1 && ncomp != 3) return fail("unsupported component count (CMYK?)");
+        if (ncomp != 1 && ncomp != 3 && ncomp != 4) return fail("unsupported component count");
         if (len != 6 + 3 * ncomp) return fail("bad SOF length");
         if ((size_t)width * height > ((size_t)1 << 28)) return fail("image too large");
         hmax = vmax = 1;                                   // a second SOF must not inherit the first one's maxima
+        rgb_ids = 0;
         for (int i = 0; i < ncomp; i++) {
             Component & c = comp[i];
             c.id = get8();
+            if (ncomp == 3 && c.id == "RGB"[i]) rgb_ids++;
             const int q = get8();
             c.h = q >> 4;
             c.v = q & 15;
@@ -577,8 +580,9 @@ struct Decoder {
             case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
                 return fail("unsupported JPEG process (lossless / arithmetic)");
             case 0xDD: if (len != 2) return fail("bad DRI"); restart_interval = get16(); break;     // (len excludes the length field itself)
+            case 0xE0: if (len >= 5 && !memcmp(p, "JFIF", 5)) saw_jfif = true; break;
             case 0xEE:
-                if (len >= 12 && !memcmp(p, "Adobe", 5)) { saw_adobe = true; adobe_transform = p[11]; }
+                if (len >= 12 && !memcmp(p, "Adobe", 6)) { saw_adobe = true; adobe_transform = p[11]; }
                 break;
             default: break;
             }
@@ -629,7 +633,7 @@ struct Decoder {
     void to_rgb(std::vector<uint8_t> & rgb) {
         rgb.resize((size_t)width * height * 3);
         struct Res { int hs, vs, ystep, ypos, wl; const uint8_t *l0, *l1; std::vector<uint8_t> buf; };
-        Res rs[3];
+        Res rs[4];
         for (int k = 0; k < ncomp; k++) {
             Component & c = comp[k];
             Res & r = rs[k];
@@ -644,7 +648,7 @@ struct Decoder {
         const int cy = (height * 1);
         (void)cy;
         for (int j = 0; j < height; j++) {
-            const uint8_t * line[3];
+            const uint8_t * line[4];
             for (int k = 0; k < ncomp; k++) {
                 Component & c = comp[k];
                 Res & r = rs[k];
@@ -664,24 +668,38 @@ struct Decoder {
                 }
             }
             uint8_t * o = &rgb[(size_t)j * width * 3];
+            // x * y / 255 rounded, for 0 <= x, y <= 255 (the multiply the reference's decoder uses for the K channel)
+            auto mul255 = [](int x, int y) { const unsigned t = (unsigned)(x * y) + 128u; return (uint8_t)((t + (t >> 8)) >> 8); };
+            auto ycc = [&](int i, uint8_t * px) {
+                const int yf = (line[0][i] << 20) + (1 << 19);
+                const int cb = line[1][i] - 128, cr = line[2][i] - 128;
+                int r = yf + cr * (((int)(1.40200f * 4096.0f + 0.5f)) << 8);
+                int g = yf + cr * -(((int)(0.71414f * 4096.0f + 0.5f)) << 8) + ((cb * -(((int)(0.34414f * 4096.0f + 0.5f)) << 8)) & 0xffff0000);
+                int b = yf + cb * (((int)(1.77200f * 4096.0f + 0.5f)) << 8);
+                r >>= 20; g >>= 20; b >>= 20;
+                px[0] = clamp8(r); px[1] = clamp8(g); px[2] = clamp8(b);
+            };
             if (ncomp == 1) {
                 for (int i = 0; i < width; i++) o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = line[0][i];
-            } else {
-                const bool is_rgb = saw_adobe && adobe_transform == 0;   // Adobe marker with transform 0: stored as RGB
+            } else if (ncomp == 3) {
+                // stored as R, G, B when the component ids say so, or under an Adobe marker with transform 0 in a file that is not JFIF
+                const bool is_rgb = rgb_ids == 3 || (saw_adobe && adobe_transform == 0 && !saw_jfif);
                 for (int i = 0; i < width; i++) {
-                    if (is_rgb) {
-                        o[3 * i] = line[0][i]; o[3 * i + 1] = line[1][i]; o[3 * i + 2] = line[2][i];
-                        continue;
+                    if (is_rgb) { o[3 * i] = line[0][i]; o[3 * i + 1] = line[1][i]; o[3 * i + 2] = line[2][i]; }
+                    else ycc(i, o + 3 * i);
+                }
+            } else {
+                // four components: Adobe transform 0 = CMYK (stored inverted: sample * K / 255), 2 = YCCK ((255 - RGB) * K / 255),
+                // anything else: YCbCr + an ignored fourth channel
+                const int tr = saw_adobe ? adobe_transform : -1;
+                for (int i = 0; i < width; i++) {
+                    uint8_t * px = o + 3 * i;
+                    const int k = line[3][i];
+                    if (tr == 0) { px[0] = mul255(line[0][i], k); px[1] = mul255(line[1][i], k); px[2] = mul255(line[2][i], k); }
+                    else {
+                        ycc(i, px);
+                        if (tr == 2) { px[0] = mul255(255 - px[0], k); px[1] = mul255(255 - px[1], k); px[2] = mul255(255 - px[2], k); }
                     }
-                    const int yf = (line[0][i] << 20) + (1 << 19);
-                    const int cb = line[1][i] - 128, cr = line[2][i] - 128;
-                    int r = yf + cr * (((int)(1.40200f * 4096.0f + 0.5f)) << 8);
-                    int g = yf + cr * -(((int)(0.71414f * 4096.0f + 0.5f)) << 8) + ((cb * -(((int)(0.34414f * 4096.0f + 0.5f)) << 8)) & 0xffff0000);
-                    int b = yf + cb * (((int)(1.77200f * 4096.0f + 0.5f)) << 8);
-                    r >>= 20; g >>= 20; b >>= 20;
-                    o[3 * i] = clamp8(r);
-                    o[3 * i + 1] = clamp8(g);
-                    o[3 * i + 2] = clamp8(b);
                 }
             }
         }

@@ -10,10 +10,10 @@ W=${FUZZ_DIR:-/tmp/clip_amd_fuzz}; IT=${1:-2000}; SEED=${2:-1}
 CL=/opt/rocm/lib/llvm/bin/clang++
 FL="-std=c++17 -g -O1 -fwrapv -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/include -I$ROOT/clip_cpp_amd/csrc"
 mkdir -p "$W/obj" "$W/seeds"
-for f in gguf quant load forward tokenizer preprocess image_io jpeg_decode host_pipeline api; do
+for f in gguf quant load forward tokenizer preprocess image_io image_formats jpeg_decode host_pipeline api; do
     $CL $FL -c "$ROOT/clip_cpp_amd/csrc/$f.cpp" -o "$W/obj/$f.o" &
 done; wait
-$CL $FL "$ROOT/scripts/fuzz/fuzz_images.cpp" "$W/obj/image_io.o" "$W/obj/jpeg_decode.o" -lz -o "$W/fuzz_images"
+$CL $FL "$ROOT/scripts/fuzz/fuzz_images.cpp" "$W/obj/image_io.o" "$W/obj/image_formats.o" "$W/obj/jpeg_decode.o" -lz -o "$W/fuzz_images"
 $CL $FL "$ROOT/scripts/fuzz/fuzz_model.cpp" "$W"/obj/*.o $(ls "$ROOT"/clip_cpp_amd/build/*.o | grep -E "/k_") -L/opt/rocm/lib -lamdhip64 -lz -lpthread -ldl -Wl,-rpath,/opt/rocm/lib -o "$W/fuzz_model"
 python3 - "$W/seeds" <<'PY'
 import sys, numpy as np, PIL.Image as I
@@ -27,6 +27,23 @@ P.convert("L").save(d + "/f.jpg"); P.convert("CMYK").save(d + "/g.jpg")
 P.save(d + "/h.png"); P.convert("P").save(d + "/i.png"); P.convert("RGBA").save(d + "/j.png"); P.convert("LA").save(d + "/k.png"); P.convert("1").save(d + "/l.png")
 I.fromarray((im.astype(np.uint16) * 257)[:, :, 0]).save(d + "/m.png")
 P.save(d + "/n.bmp"); P.convert("RGBA").save(d + "/o.bmp"); P.save(d + "/p.ppm")
+# image_formats.cpp: paletted / 1-bit BMP, TGA (raw, RLE, colour-mapped, grey + alpha), GIF (plain, interlaced + transparent), 16-bit PGM, PSD (PackBits, 4 channels)
+P.convert("P").save(d + "/q.bmp"); P.convert("1").save(d + "/r.bmp")
+P.save(d + "/s.tga"); P.convert("RGBA").save(d + "/t.tga", compression="tga_rle"); P.convert("P").save(d + "/u.tga"); P.convert("LA").save(d + "/v.tga", compression="tga_rle")
+P.convert("P").save(d + "/w.gif"); P.convert("P", palette=1, colors=17).save(d + "/x.gif", interlace=True, transparency=3)
+open(d + "/y.pgm", "wb").write(b"P5\n53 37\n65535\n" + (im[:, :, 0].astype(">u2") * 257).tobytes())
+import struct
+def packbits(row):
+    out, i = bytearray(), 0
+    while i < len(row):
+        run = 1
+        while i + run < len(row) and run < 128 and row[i + run] == row[i]: run += 1
+        if run > 1: out += bytes((257 - run, row[i])); i += run
+        else: out += bytes((0, row[i])); i += 1
+    return bytes(out)
+pl = np.concatenate([np.moveaxis(im, -1, 0), (im[None, :, :, 0] // 2 + 100)]).astype(np.uint8)
+rows = [packbits(bytes(pl[c, y])) for c in range(4) for y in range(37)]
+open(d + "/z.psd", "wb").write(b"8BPS" + struct.pack(">H6xHIIHH", 1, 4, 37, 53, 8, 3) + struct.pack(">III", 0, 0, 0) + struct.pack(">H", 1) + b"".join(struct.pack(">H", len(r)) for r in rows) + b"".join(rows))
 PY
 export ASAN_OPTIONS=detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=4096
 "$W/fuzz_images" "$IT" "$W/t.bin" "$SEED" "$W"/seeds/* 2>&1 | grep -E "runtime error|ERROR|SUMMARY|decoded$|#[0-9]" | tail -20
