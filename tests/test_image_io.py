@@ -536,3 +536,40 @@ def test_jpeg_four_components_and_rgb_equal_reference_decoder(clip_lib, stb, tmp
     same(_jpeg_patch(rgb, adobe_transform=0, drop_app0=True))                       # ... without JFIF: RGB
     same(_jpeg_patch(rgb, adobe_transform=1, drop_app0=True))
     same(_jpeg_patch(rgb, drop_app0=True))
+
+
+def _png(w, h, depth, ctype, filtered_rows, plte=None, trns=None, interlace=0):
+    import zlib
+    chunk = lambda t, b: struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+    if plte is not None:
+        out += chunk(b"PLTE", plte)
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    return out + chunk(b"IDAT", zlib.compress(filtered_rows)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 2), (5, 3), (8, 8), (17, 9), (33, 13)])
+def test_png_pixels_equal_reference_decoder(clip_lib, stb, tmp_path, w, h):
+    """Random filtered scanlines of every colour type x bit depth x filter type, with and without tRNS, plain and Adam7 (which PIL cannot write)."""
+    rng = np.random.default_rng(w * 64 + h)
+    same = lambda data: _same_as_reference(clip_lib, stb, tmp_path, data, "t.png")
+    xs, ys, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    for ctype, chans in ((0, 1), (2, 3), (3, 1), (4, 2), (6, 4)):
+        for depth in (1, 2, 4, 8, 16):
+            if (ctype in (2, 4, 6) and depth < 8) or (ctype == 3 and depth == 16):
+                continue
+            plte = bytes(rng.integers(0, 256, 3 << min(depth, 8), dtype=np.uint8)) if ctype == 3 else None
+            trns = {0: b"\x00\x01", 2: b"\x00\x01\x00\x02\x00\x03", 3: b"\x00\x80"}.get(ctype)
+            row = lambda pw, f: bytes((f,)) + bytes(rng.integers(0, 256, (pw * chans * depth + 7) // 8, dtype=np.uint8))
+            for f in range(5):
+                rows = b"".join(row(w, f) for _ in range(h))
+                same(_png(w, h, depth, ctype, rows, plte))
+                if trns:
+                    same(_png(w, h, depth, ctype, rows, plte, trns))
+            raw = b""
+            for p in range(7):
+                pw, ph = (w - xs[p] + dx[p] - 1) // dx[p], (h - ys[p] + dy[p] - 1) // dy[p]
+                if pw > 0 and ph > 0:
+                    raw += b"".join(row(pw, int(rng.integers(0, 5))) for _ in range(ph))
+            same(_png(w, h, depth, ctype, raw, plte, interlace=1))
