@@ -4,9 +4,10 @@
 // GIF (first frame), PSD (RGB, 8 / 16 bit, raw / PackBits) and binary PNM with any maxval.  Host side, outside the GPU hot path
 // (SURVEY §2 #7); own decoders.  The pixels feed the bit-exact preprocessing, so wherever a format leaves room (5-bit channel
 // scaling, un-matting of PSD alpha, what a GIF's undrawn pixels are) the arithmetic follows what the reference's decoder does for
-// the same bytes — tests/test_image_io.py compares every case with that decoder (oracle/_ref/libstb_ref.so).  Softimage PIC and
-// Radiance HDR are not read.
+// the same bytes — tests/test_image_io.py compares every case with that decoder (oracle/_ref/libstb_ref.so).  Also here, for
+// completeness of that list: Softimage PIC and Radiance RGBE (.hdr, tone-mapped to 8 bits with gamma 2.2 as the reference does).
 #include <climits>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -562,6 +563,182 @@ bool decode_pnm_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb,
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Softimage PIC
+// ------------------------------------------------------------------------------------------------------------------
+bool decode_pic_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
+    static const uint8_t magic[4] = {0x53, 0x80, 0xF6, 0x34};
+    if (d.size() < 92 || memcmp(d.data(), magic, 4) != 0 || memcmp(d.data() + 88, "PICT", 4) != 0) return false;
+    Reader r(d);
+    r.skip(92);
+    const int w = r.u16be(), h = r.u16be();
+    if (r.at_end() || !pixels_fit(w, h)) return false;
+    r.skip(8);                                              // ratio, fields, pad
+    struct Packet { int type, channels; } pk[10];
+    int n_pk = 0, chained;
+    do {                                                    // channel packets: which of R G B A (bits 7..4) a run of the scanline data carries, and how it is packed
+        if (n_pk == 10) return false;
+        chained = r.u8();
+        const int bits = r.u8();
+        pk[n_pk].type = r.u8();
+        pk[n_pk].channels = r.u8();
+        n_pk++;
+        if (r.at_end() || bits != 8) return false;
+    } while (chained);
+    const size_t n = (size_t)w * h;
+    std::vector<uint8_t> px(n * 4, 0xff);
+    auto read_px = [&](int channels, uint8_t * dst) {       // false: the file ends inside a pixel
+        for (int i = 0, m = 0x80; i < 4; i++, m >>= 1)
+            if (channels & m) { if (r.at_end()) return false; dst[i] = (uint8_t)r.u8(); }
+        return true;
+    };
+    auto copy_px = [](int channels, uint8_t * dst, const uint8_t * src) {
+        for (int i = 0, m = 0x80; i < 4; i++, m >>= 1) if (channels & m) dst[i] = src[i];
+    };
+    for (int y = 0; y < h; y++)
+        for (int k = 0; k < n_pk; k++) {
+            uint8_t * dst = &px[(size_t)y * w * 4];
+            const int ch = pk[k].channels;
+            if (pk[k].type == 0) {                          // raw
+                for (int x = 0; x < w; x++, dst += 4) if (!read_px(ch, dst)) return false;
+            } else if (pk[k].type == 1) {                   // runs only: count, value
+                int left = w;
+                while (left > 0) {
+                    int count = r.u8();
+                    if (r.at_end()) return false;
+                    if (count > left) count = left;
+                    uint8_t v[4];
+                    if (!read_px(ch, v)) return false;
+                    for (int i = 0; i < count; i++, dst += 4) copy_px(ch, dst, v);
+                    left -= count;
+                }
+            } else if (pk[k].type == 2) {                   // mixed: >= 128 a run (128: 16-bit length follows), < 128 count + 1 raw pixels
+                int left = w;
+                while (left > 0) {
+                    int count = r.u8();
+                    if (r.at_end()) return false;
+                    if (count >= 128) {
+                        count = count == 128 ? r.u16be() : count - 127;
+                        if (count > left) return false;
+                        uint8_t v[4];
+                        if (!read_px(ch, v)) return false;
+                        for (int i = 0; i < count; i++, dst += 4) copy_px(ch, dst, v);
+                    } else {
+                        count++;
+                        if (count > left) return false;
+                        for (int i = 0; i < count; i++, dst += 4) if (!read_px(ch, dst)) return false;
+                    }
+                    left -= count;
+                }
+            } else return false;
+        }
+    nx = w; ny = h;
+    rgb.resize(n * 3);
+    for (size_t i = 0; i < n; i++) { rgb[i * 3] = px[i * 4]; rgb[i * 3 + 1] = px[i * 4 + 1]; rgb[i * 3 + 2] = px[i * 4 + 2]; }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Radiance RGBE (.hdr): decoded to float, then to 8 bits the way the reference's loader does for an 8-bit request
+// (value ^ (1 / 2.2) * 255 + 0.5, clamped, truncated)
+// ------------------------------------------------------------------------------------------------------------------
+bool decode_hdr_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) {
+    if (!((d.size() >= 11 && !memcmp(d.data(), "#?RADIANCE\n", 11)) || (d.size() >= 7 && !memcmp(d.data(), "#?RGBE\n", 7)))) return false;
+    Reader r(d);
+    auto line = [&]() {                                     // up to the next newline; over-long lines are cut at 1022 characters
+        std::string t;
+        int c = r.u8();
+        while (!r.at_end() && c != '\n') {
+            t.push_back((char)c);
+            if (t.size() == 1023) { while (!r.at_end() && r.u8() != '\n') {} break; }
+            c = r.u8();
+        }
+        const size_t z = t.find('\0');                      // (the reference compares C strings)
+        if (z != std::string::npos) t.resize(z);
+        return t;
+    };
+    const std::string id = line();
+    if (id != "#?RADIANCE" && id != "#?RGBE") return false;
+    bool rgbe = false;
+    for (;;) {
+        const std::string t = line();
+        if (t.empty()) break;
+        if (t == "FORMAT=32-bit_rle_rgbe") rgbe = true;
+    }
+    if (!rgbe) return false;
+    const std::string res = line();
+    if (res.compare(0, 3, "-Y ") != 0) return false;
+    const char * q = res.c_str() + 3;
+    char * e = nullptr;
+    const long h = strtol(q, &e, 10);
+    while (*e == ' ') e++;
+    if (strncmp(e, "+X ", 3) != 0) return false;
+    const long w = strtol(e + 3, nullptr, 10);
+    if (!pixels_fit(w, h)) return false;
+    const size_t n = (size_t)w * h;
+    std::vector<float> f(n * 3);
+    auto to_float = [](float * o, const uint8_t * in) {
+        if (in[3] != 0) {
+            const float s = (float)ldexp(1.0f, (int)in[3] - (128 + 8));
+            o[0] = in[0] * s; o[1] = in[1] * s; o[2] = in[2] * s;
+        } else o[0] = o[1] = o[2] = 0.f;
+    };
+    auto flat_from = [&](size_t first) {                    // four bytes per pixel, no packing
+        for (size_t i = first; i < n; i++) {
+            uint8_t q4[4] = {0, 0, 0, 0};
+            if ((size_t)(r.end - r.p) >= 4) { memcpy(q4, r.p, 4); r.p += 4; }   // (a short tail is left as it is by the reference: zeros here)
+            else r.p = r.end;
+            to_float(&f[i * 3], q4);
+        }
+    };
+    if (w < 8 || w >= 32768) flat_from(0);
+    else {
+        std::vector<uint8_t> scan((size_t)w * 4);
+        for (long y = 0; y < h; y++) {
+            const int c1 = r.u8(), c2 = r.u8();
+            int len = r.u8();
+            if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+                // not a packed scanline: the reference takes these four bytes for pixel 0 and reads the REST OF THE IMAGE flat from
+                // here, whichever scanline it was in
+                const uint8_t q4[4] = {(uint8_t)c1, (uint8_t)c2, (uint8_t)len, (uint8_t)r.u8()};
+                to_float(&f[0], q4);
+                flat_from(1);
+                break;
+            }
+            len = (len << 8) | r.u8();
+            if (len != w) return false;
+            for (int k = 0; k < 4; k++) {
+                long i = 0;
+                while (i < w) {
+                    int count = r.u8();
+                    if (count > 128) {
+                        const int v = r.u8();
+                        count -= 128;
+                        if (count > w - i) return false;
+                        for (int z = 0; z < count; z++) scan[(size_t)(i++) * 4 + k] = (uint8_t)v;
+                    } else {
+                        if (count == 0 || count > w - i) return false;
+                        for (int z = 0; z < count; z++) scan[(size_t)(i++) * 4 + k] = (uint8_t)r.u8();
+                    }
+                }
+            }
+            for (long i = 0; i < w; i++) to_float(&f[((size_t)y * w + i) * 3], &scan[(size_t)i * 4]);
+        }
+    }
+    nx = (int)w; ny = (int)h;
+    rgb.resize(n * 3);
+    const float scale = 1.0f, inv_gamma = 1.0f / 2.2f;
+    for (size_t i = 0; i < n * 3; i++) {
+        const float lin = f[i] * scale;
+        float z = (float)pow((double)lin, (double)inv_gamma) * 255 + 0.5f;
+        if (z < 0) z = 0;
+        if (z > 255) z = 255;
+        rgb[i] = (uint8_t)(int)z;
+    }
+    return true;
+}
+
 }  // namespace
 
 bool decode_bmp(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) { return decode_bmp_impl(d, rgb, nx, ny); }
@@ -569,5 +746,7 @@ bool decode_tga(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
 bool decode_gif(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) { return decode_gif_impl(d, rgb, nx, ny); }
 bool decode_psd(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) { return decode_psd_impl(d, rgb, nx, ny); }
 bool decode_pnm(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) { return decode_pnm_impl(d, rgb, nx, ny); }
+bool decode_pic(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) { return decode_pic_impl(d, rgb, nx, ny); }
+bool decode_hdr(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny) { return decode_hdr_impl(d, rgb, nx, ny); }
 
 }  // namespace clipamd

@@ -2,7 +2,7 @@
 // stb_image).  Host-side and outside the GPU hot path.  Own decoders, 3-channel RGB
 // output like stbi_load(..., 3): PNG here (8/16-bit, all colour types, non-interlaced and Adam7, inflate
 // via zlib), JPEG in jpeg_decode.cpp (baseline + progressive Huffman, grey / YCbCr / RGB / CMYK / YCCK),
-// BMP / GIF / PSD / PNM / TGA in image_formats.cpp.  Formats are tried in the reference decoder's order.
+// BMP / GIF / PSD / PIC / PNM / HDR / TGA in image_formats.cpp.  Formats are tried in the reference decoder's order.
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -22,6 +22,8 @@ bool decode_gif(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
 bool decode_psd(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
 bool decode_pnm(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
 bool decode_tga(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
+bool decode_pic(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
+bool decode_hdr(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int & nx, int & ny);
 
 namespace {
 
@@ -173,7 +175,8 @@ bool load_image_file(const char * fname, clip_image_u8 * img) {
     if (ok) {
         // (the order of the reference's decoder: formats with a magic number first, TGA — which has none — last)
         ok = decode_png(d, rgb, nx, ny) || decode_bmp(d, rgb, nx, ny) || decode_gif(d, rgb, nx, ny) || decode_psd(d, rgb, nx, ny) ||
-             decode_jpeg(d.data(), d.size(), rgb, nx, ny, err) || decode_pnm(d, rgb, nx, ny) || decode_tga(d, rgb, nx, ny);
+             decode_pic(d, rgb, nx, ny) || decode_jpeg(d.data(), d.size(), rgb, nx, ny, err) || decode_pnm(d, rgb, nx, ny) || decode_hdr(d, rgb, nx, ny) ||
+             decode_tga(d, rgb, nx, ny);
     }
     if (!ok) {
         fprintf(stderr, "%s: failed to load '%s'%s%s\n", "clip_image_load_from_file", fname, err.empty() ? "" : ": ", err.c_str());

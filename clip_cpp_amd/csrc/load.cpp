@@ -232,6 +232,11 @@ struct Loader {
     }
 
     bool layers(const char * prefix, int n_layer, int h, int ff, std::vector<DevLayer> & L) {
+        // a layer is 16 tensors of the file: a block count the file cannot hold (corrupt / hostile metadata) is refused before anything is sized by it
+        if (n_layer < 0 || (size_t)n_layer > g.tensors.size() / 16) {
+            if (err.empty()) err = "block_count " + std::to_string(n_layer) + " exceeds the tensors in the file";
+            return false;
+        }
         L.resize(n_layer);
         char b[96];
         for (int i = 0; i < n_layer; i++) {

@@ -1,6 +1,6 @@
 #!/bin/bash
-# ASan + UBSan mutation runs over the two parsers of untrusted files: the image decoders (clip_image_load_from_file: PNM / BMP / PNG /
-# JPEG) and the GGUF reader + loader + quantizer (clip_model_load on a host-only context, clip_model_quantize).  CPU only.
+# ASan + UBSan mutation runs over the two parsers of untrusted files: the image decoders (clip_image_load_from_file: PNG / BMP / GIF / PSD /
+# PIC / JPEG / PNM / HDR / TGA) and the GGUF reader + loader + quantizer (clip_model_load on a host-only context, clip_model_quantize).  CPU only.
 #   scripts/fuzz/run.sh [iterations-per-seed] [rng-seed]
 # Host sources are compiled as C++ with clang's sanitizers and linked against the kernel objects of the normal build
 # (python -m clip_cpp_amd.build first).  Seeds: small PIL-written images, the tiny fixtures of oracle/fixtures.py.
@@ -43,6 +43,9 @@ def packbits(row):
     return bytes(out)
 pl = np.concatenate([np.moveaxis(im, -1, 0), (im[None, :, :, 0] // 2 + 100)]).astype(np.uint8)
 rows = [packbits(bytes(pl[c, y])) for c in range(4) for y in range(37)]
+open(d + "/za.hdr", "wb").write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 37 +X 53\n" + b"".join(bytes((2, 2, 0, 53)) + b"".join(b"".join(bytes((1, int(v))) for v in im[y, :, k]) for k in range(3)) + bytes((128 + 53, 129)) for y in range(37)))
+open(d + "/zb.hdr", "wb").write(b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y 5 +X 7\n" + np.concatenate([im[:5, :7], np.full((5, 7, 1), 130, np.uint8)], -1).tobytes())
+open(d + "/zc.pic", "wb").write(b"\x53\x80\xf6\x34" + bytes(84) + b"PICT" + struct.pack(">HHfHH", 53, 37, 1.0, 3, 0) + bytes((1, 8, 2, 0xE0, 0, 8, 1, 0x10)) + b"".join(b"".join(bytes((26,)) + im[y, x:x + 27].tobytes() for x in (0, 27))[:2 + 53 * 3] + bytes((53, 200)) for y in range(37)))
 open(d + "/z.psd", "wb").write(b"8BPS" + struct.pack(">H6xHIIHH", 1, 4, 37, 53, 8, 3) + struct.pack(">III", 0, 0, 0) + struct.pack(">H", 1) + b"".join(struct.pack(">H", len(r)) for r in rows) + b"".join(rows))
 PY
 export ASAN_OPTIONS=detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=4096

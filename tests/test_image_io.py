@@ -182,7 +182,7 @@ def _bmp(w, h, bpp, rows, palette=None, hsz=40, comp=0, masks=None, top_down=Fal
     else:
         hdr = struct.pack("<IiiHHIIiiII", hsz, w, -h if top_down else h, 1, bpp, comp, len(body), 2835, 2835, 0, 0)
         if hsz == 56:
-            hdr += struct.pack("<IIII", *(masks or (0, 0, 0)), 0) if False else b"\0" * 16
+            hdr += b"\0" * 16
         if hsz in (108, 124):
             m = masks or (0, 0, 0, 0)
             hdr += struct.pack("<IIII", *(tuple(m) + (0,) * (4 - len(m)))) + b"\0" * (4 + 48) + (b"\0" * 16 if hsz == 124 else b"")
@@ -416,8 +416,7 @@ def test_gif_first_frame_equals_reference_decoder(clip_lib, stb, tmp_path, W, H)
     same(_pil_bytes(pim.convert("P", palette=1, colors=17), "GIF", transparency=3))
     # no image at all / no colour table / truncated raster
     same(b"GIF89a" + struct.pack("<HHBBB", W, H, 0, 0, 0) + b"\x3b", must_load=False)
-    same(_gif(W, H, (0, 0, W, H, np.zeros(W * H, int)), gpal=[(1, 2, 3), (4, 5, 6)]).replace(b"\x80", b"\x00", 1) if False else
-         b"GIF89a" + struct.pack("<HHBBB", W, H, 0, 0, 0) + b"\x2c" + struct.pack("<HHHHB", 0, 0, W, H, 0) + b"\x02\x02\x4c\x01\0\x3b", must_load=False)
+    same(b"GIF89a" + struct.pack("<HHBBB", W, H, 0, 0, 0) + b"\x2c" + struct.pack("<HHHHB", 0, 0, W, H, 0) + b"\x02\x02\x4c\x01\0\x3b", must_load=False)
     data = _gif(W, H, (0, 0, W, H, rng.integers(0, 16, W * H)), gpal=[(i * 16, 255 - i * 16, i) for i in range(16)])
     same(data[:len(data) * 2 // 3], must_load=False)
 
@@ -573,3 +572,115 @@ def test_png_pixels_equal_reference_decoder(clip_lib, stb, tmp_path, w, h):
                 if pw > 0 and ph > 0:
                     raw += b"".join(row(pw, int(rng.integers(0, 5))) for _ in range(ph))
             same(_png(w, h, depth, ctype, raw, plte, interlace=1))
+
+
+def _pic(w, h, packets, rows):
+    """packets: [(type, channel mask)]; rows[y][k] = the bytes of packet k on scanline y."""
+    hdr = b"\x53\x80\xf6\x34" + struct.pack(">f", 3.71) + b"made by a test".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", w, h, 1.0, 3, 0)
+    pk = b"".join(struct.pack("BBBB", 1 if i + 1 < len(packets) else 0, 8, t, ch) for i, (t, ch) in enumerate(packets))
+    return hdr + pk + b"".join(b"".join(r) for r in rows)
+
+
+def _pic_encode(vals, type_, rng):
+    """vals: [w][n channels] uint8 of one packet on one scanline."""
+    w = len(vals)
+    if type_ == 0:
+        return vals.tobytes()
+    out, i = bytearray(), 0
+    while i < w:
+        run = 1
+        while i + run < w and run < 255 and np.array_equal(vals[i + run], vals[i]):
+            run += 1
+        if type_ == 1:
+            out += bytes((run,)) + vals[i].tobytes()
+            i += run
+        elif run > 1 and rng.random() < 0.8:
+            if rng.random() < 0.3:
+                out += b"\x80" + struct.pack(">H", run) + vals[i].tobytes()        # 16-bit run length
+            else:
+                run = min(run, 128)
+                out += bytes((127 + run,)) + vals[i].tobytes()
+            i += run
+        else:
+            lit = int(min(w - i, rng.integers(1, 129)))
+            out += bytes((lit - 1,)) + vals[i:i + lit].tobytes()
+            i += lit
+    return bytes(out)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (300, 5)])
+def test_softimage_pic_equals_reference_decoder(clip_lib, stb, tmp_path, w, h):
+    rng = np.random.default_rng(w + 7 * h)
+    same = lambda data, **kw: _same_as_reference(clip_lib, stb, tmp_path, data, "t.pic", **kw)
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    img[:, rng.random(w) < 0.6] = img[0, 0]
+    for layout in ([(0, 0xE0)], [(1, 0xE0)], [(2, 0xE0)], [(2, 0xE0), (2, 0x10)], [(0, 0x80), (1, 0x40), (2, 0x20)], [(2, 0xF0)], [(2, 0x60)]):
+        sel = lambda ch: [i for i, m in enumerate((0x80, 0x40, 0x20, 0x10)) if ch & m]
+        rows = [[_pic_encode(np.ascontiguousarray(img[y][:, sel(ch)]), t, rng) for t, ch in layout] for y in range(h)]
+        got = same(_pic(w, h, layout, rows))
+        if layout[0][1] == 0xE0:
+            assert np.array_equal(got, img[:, :, :3])
+    # refused by ours; the reference crashes on a corrupt PIC (it converts a NULL image), so these are not handed to it
+    for bad in (_pic(w, h, [(3, 0xE0)], [[b"\0" * 3 * w]] * h), _pic(w, h, [(0, 0xE0)], [[img[y, :, :3].tobytes()] for y in range(h)])[:-2]):
+        path = str(tmp_path / "bad.pic")
+        open(path, "wb").write(bad)
+        assert load_ours(clip_lib, path) is None
+
+
+def _rgbe(rgbf):
+    """float RGB [n][3] -> RGBE bytes [n][4] (Ward's shared-exponent encoding)."""
+    m = rgbf.max(axis=1)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(int)
+    out = np.zeros((len(rgbf), 4), dtype=np.uint8)
+    ok = m > 1e-32
+    out[ok, :3] = np.clip(rgbf[ok] * (256.0 / (2.0 ** e[ok]))[:, None], 0, 255).astype(np.uint8)
+    out[ok, 3] = (e[ok] + 128).astype(np.uint8)
+    return out
+
+
+def _hdr(w, h, px, rle, ident=b"#?RADIANCE", extra=b"EXPOSURE=1.0\n"):
+    head = ident + b"\n" + extra + b"FORMAT=32-bit_rle_rgbe\n\n" + b"-Y %d +X %d\n" % (h, w)
+    if not rle:
+        return head + px.tobytes()
+    body = bytearray()
+    for y in range(h):
+        row = px[y * w:(y + 1) * w]
+        body += bytes((2, 2, w >> 8, w & 255))
+        for k in range(4):
+            col, i = row[:, k], 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and col[i + run] == col[i]:
+                    run += 1
+                if run > 2:
+                    body += bytes((128 + run, col[i]))
+                    i += run
+                else:
+                    lit = 1
+                    while i + lit < w and lit < 128 and not (i + lit + 2 < w and col[i + lit] == col[i + lit + 1] == col[i + lit + 2]):
+                        lit += 1
+                    body += bytes((lit,)) + col[i:i + lit].tobytes()
+                    i += lit
+    return head + bytes(body)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 4), (8, 3), (200, 6)])
+def test_radiance_hdr_equals_reference_decoder(clip_lib, stb, tmp_path, w, h):
+    rng = np.random.default_rng(w * 3 + h)
+    same = lambda data, **kw: _same_as_reference(clip_lib, stb, tmp_path, data, "t.hdr", **kw)
+    rgbf = np.exp(rng.normal(-1.0, 2.0, (w * h, 3)))                                  # 0.001 ... 50: under-, mid- and over-exposed
+    rgbf[rng.random(w * h) < 0.1] = 0.0
+    rgbf[rng.random(w * h) < 0.4] = rgbf[0]
+    px = _rgbe(rgbf)
+    same(_hdr(w, h, px, rle=False))                                                  # flat (also what a wide file may hold: "not a packed scanline")
+    same(_hdr(w, h, px, rle=False, ident=b"#?RGBE", extra=b""))
+    if w >= 8:
+        same(_hdr(w, h, px, rle=True))
+        same(_hdr(w, h, px, rle=True, extra=b"# comment line\nGAMMA=1\nPRIMARIES=0.640 0.330 0.290 0.600 0.150 0.060 0.333 0.333\n"))
+        # a later scanline that is not packed: the reference restarts flat at pixel 0 from there
+        first = _hdr(w, 1, px[:w], rle=True)
+        head = _hdr(w, h, px, rle=False)[:-(w * h * 4)]
+        one_packed_row = first[len(_hdr(w, 1, px[:w], rle=False)) - w * 4:]
+        same(head + one_packed_row + px[w:].tobytes() + bytes(4 * w), must_load=False)
+    same(_hdr(w, h, px, rle=False).replace(b"FORMAT=32-bit_rle_rgbe", b"FORMAT=32-bit_rle_xyze"), must_load=False)
+    same(_hdr(w, h, px, rle=False).replace(b"-Y ", b"+Y "), must_load=False)

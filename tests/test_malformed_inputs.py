@@ -59,6 +59,13 @@ if mode == "images":
                     ("PNG", {}), ("BMP", {}), ("PPM", {})):
         b = io.BytesIO(); P.save(b, fmt, **kw); seeds.append(b.getvalue())
     b = io.BytesIO(); P.convert("P").save(b, "PNG"); seeds.append(b.getvalue())
+    # image_formats.cpp: paletted BMP, TGA (RLE), GIF, CMYK JPEG, and hand-made PSD / HDR / PIC
+    for mode_, fmt, kw in (("P", "BMP", {}), ("RGBA", "TGA", dict(compression="tga_rle")), ("P", "GIF", {}), ("CMYK", "JPEG", {})):
+        b = io.BytesIO(); P.convert(mode_).save(b, fmt, **kw); seeds.append(b.getvalue())
+    import struct
+    seeds.append(b"8BPS" + struct.pack(">H6xHIIHH", 1, 4, 29, 41, 8, 3) + struct.pack(">III", 0, 0, 0) + struct.pack(">H", 0) + np.moveaxis(np.concatenate([im, im[:, :, :1] // 2 + 90], -1), -1, 0).tobytes())
+    seeds.append(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 29 +X 41\n" + b"".join(bytes((2, 2, 0, 41)) + b"".join(bytes((41,)) + np.ascontiguousarray(im[y, :, k]).tobytes() for k in range(3)) + bytes((128 + 41, 129)) for y in range(29)))
+    seeds.append(b"\x53\x80\xf6\x34" + bytes(84) + b"PICT" + struct.pack(">HHfHH", 41, 29, 1.0, 3, 0) + bytes((0, 8, 0, 0xE0)) + im.tobytes())
     for s in seeds:
         for it in range(%(iters)d):
             open(tmp, "wb").write(s if it == 0 else mutate(s))
@@ -98,7 +105,7 @@ def _run(mode, tmp_path, iters, models=()):
 def test_mutated_image_files_never_crash_the_decoders(clip_lib, tmp_path):
     pytest.importorskip("PIL.Image")
     done, ok = _run("images", tmp_path, 120)
-    assert done == 7 * 120 and 7 <= ok < done          # the unmutated seeds decode, some mutations do not
+    assert done == 14 * 120 and 14 <= ok < done        # the unmutated seeds decode, some mutations do not
 
 
 def test_mutated_gguf_files_never_crash_load_or_quantize(clip_lib, tmp_path, fixture_cache):
@@ -106,3 +113,33 @@ def test_mutated_gguf_files_never_crash_load_or_quantize(clip_lib, tmp_path, fix
               fixtures.cached_model(fixture_cache, "tiny", "f32", text=False, vision=True)]
     done, ok = _run("gguf", tmp_path, 100, models)
     assert done == 200 and 2 <= ok < done
+
+
+def test_block_count_larger_than_the_file_is_refused(clip_lib, tmp_path, fixture_cache):
+    """A block count the file's tensors cannot cover (hostile metadata: round-5 sanitizer finding, a 343 GB std::vector) fails the load cleanly."""
+    import struct
+    path = fixtures.cached_model(fixture_cache, "tiny", "q4_1", text=False, vision=True)
+    d = bytearray(open(path, "rb").read())
+    key = b"clip.vision.block_count"
+    at = d.index(key) + len(key)
+    assert struct.unpack("<I", d[at:at + 4])[0] == 4                     # GGUF value type: u32
+    n = struct.unpack("<I", d[at + 4:at + 8])[0]
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+os.environ["CLIP_AMD_ALLOW_NO_DEVICE"] = "1"
+os.environ["CLIP_AMD_WEIGHT_CACHE"] = "0"
+import clip_cpp_amd
+L = clip_cpp_amd.lib()
+for v in (%d, 0x7fffffff, 0x50000000):
+    d = bytearray(open(%r, "rb").read())
+    d[%d:%d] = v.to_bytes(4, "little")
+    open(%r, "wb").write(d)
+    ctx = L.clip_model_load(os.fsencode(%r), 0)
+    print("LOADED" if ctx else "REFUSED", v)
+    if ctx: L.clip_free(ctx)
+""" % (ROOT, n, path, at + 4, at + 8, str(tmp_path / "bc.gguf"), str(tmp_path / "bc.gguf"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, errors="replace", timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = re.findall(r"(LOADED|REFUSED) (\d+)", r.stdout)
+    assert out == [("LOADED", str(n)), ("REFUSED", str(0x7fffffff)), ("REFUSED", str(0x50000000))], r.stdout[-500:] + r.stderr[-500:]
