@@ -122,6 +122,11 @@ def self_launch(n):
     raise SystemExit(proc.wait())
 
 
+def frac4(x):
+    """A roofline fraction for the JSON line: 4 decimals, but never rounded to 0 (tiny test models sit at 1e-5: 3 significant digits there)."""
+    return round(x, 4) if x >= 0.01 else float("%.3g" % x)
+
+
 def kernel_source_sha16():
     """Identity of the kernel sources a PMC traffic file was measured at (profiles/pmc_traffic.json carries it)."""
     h = hashlib.sha256()
@@ -262,8 +267,8 @@ def matrix_cell(torch, clip_cpp_amd, synth, cache, name, local_rank, steps=None,
     # whole_step_frac_survey_flops is the same time against the SURVEY 8(d) per-item figure
     out = {"name": name, "value": round((batch + n_texts) * steps / dt, 1), "unit": "embeddings/s" if n_texts else "images/s",
            "ms_per_step": round(ms, 4), "ms_per_step_median": round(sm[len(sm) // 2], 4), "steps": steps, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
-           "t_bound_us": round(max(t_mfma, t_hbm) * 1e6, 2), "whole_step_frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 4),
-           "whole_step_frac_survey_flops": round(max(t_mfma_survey, t_hbm) / (ms * 1e-3), 4)}
+           "t_bound_us": round(max(t_mfma, t_hbm) * 1e6, 2), "whole_step_frac": frac4(max(t_mfma, t_hbm) / (ms * 1e-3)),
+           "whole_step_frac_survey_flops": frac4(max(t_mfma_survey, t_hbm) / (ms * 1e-3))}
     # rows of THIS cell's timed call kept for the oracle comparison of the cpu_baseline leg (first / last image, first / last text; the
     # wide models two rows, the narrow ones four): the comparison runs after every timed region, never inside one
     k = 2 if vc["hidden_size"] >= 1024 else 4
@@ -380,8 +385,8 @@ def single_process_main(args, cfg, steps, batch, n_texts, torch, clip_cpp_amd, s
                                                                                            (" + %d texts" % n_texts) if n_texts else ""),
                       "name": args.config, "images_per_gpu": batch, "texts_per_gpu": n_texts, "parallelism": "dp%d single-process" % N},
            "whole_step_roofline": {"bound": "mfma" if t_mfma_ws >= t_hbm_ws else "hbm", "algorithmic_flops_per_step": fl_step, "executed_flops_per_step": fl_exec,
-                                   "algorithmic_bytes_per_step": by_step, "frac": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4),
-                                   "frac_survey_flops": round(max(fl_step / (MFMA_F16_PEAK_TFLOPS * 1e12), t_hbm_ws) / (ms_step * 1e-3), 4),
+                                   "algorithmic_bytes_per_step": by_step, "frac": frac4(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3)),
+                                   "frac_survey_flops": frac4(max(fl_step / (MFMA_F16_PEAK_TFLOPS * 1e12), t_hbm_ws) / (ms_step * 1e-3)),
                                    "note": "per GPU; frac counts executed FLOPs"},
            "roofline": None, "cpu_baseline": None,
            "parity": "partial (the oracle's op arithmetic is unpinned against ggml — the reference ships no vectors and its ggml submodule is absent; its graph wiring, loader, tokenizer and preprocessing are bit-identical to the reference's own clip.cpp run over oracle/ggml_shim)"}
@@ -641,8 +646,8 @@ def main():
     whole = {"bound": ws_bound, "algorithmic_flops_per_step": fl_step, "executed_flops_per_step": fl_exec, "algorithmic_bytes_per_step": by_step,
              "t_mfma_us": round(t_mfma_ex * 1e6, 2), "t_hbm_us": round(t_hbm_ws * 1e6, 2),
              "achieved_tflops": round(fl_exec / (ms_step * 1e-3) / 1e12, 2), "achieved_gbs": round(by_step / (ms_step * 1e-3) / 1e9, 1),
-             "frac": round(max(t_mfma_ex, t_hbm_ws) / (ms_step * 1e-3), 4),
-             "frac_survey_flops": round(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3), 4),
+             "frac": frac4(max(t_mfma_ex, t_hbm_ws) / (ms_step * 1e-3)),
+             "frac_survey_flops": frac4(max(t_mfma_ws, t_hbm_ws) / (ms_step * 1e-3)),
              "achieved_tflops_survey_flops": round(fl_step / (ms_step * 1e-3) / 1e12, 2),
              "executed_note": ("frac and achieved_tflops use executed_flops_per_step — what the kernels multiply: the last layer's out-projection + FFN run on the "
                                "pooled row of every sequence only (same embeddings); *_survey_flops use the SURVEY 8(d) per-item figure over the same step time")}
@@ -711,10 +716,10 @@ def main():
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             gbs_w = wb_l / (avg_ms * 1e-3) / 1e9
             mfma_view = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4)}
-            hbm_w_view = {"bound": "hbm", "achieved": round(gbs_w, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_w / HBM_PEAK_GBS, 4),
+                         "frac": frac4(achieved / MFMA_F16_PEAK_TFLOPS)}
+            hbm_w_view = {"bound": "hbm", "achieved": round(gbs_w, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac4(gbs_w / HBM_PEAK_GBS),
                           "note": "weight bytes only (SURVEY 8d)"}
-            hbm_k_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            hbm_k_view = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac4(gbs / HBM_PEAK_GBS),
                           "note": "kernel-level view: weights + activations + outputs + residual rows of the launch"}
             mfma_bound = t_mfma >= t_hbm_w          # FLOPs per weight byte above the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)
             roofline = dict(mfma_view if mfma_bound else hbm_w_view)
