@@ -83,13 +83,14 @@ bool decode_bmp_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb,
     if (hsz != 12) {
         const int32_t comp = (int32_t)r.u32le();
         if (comp == 1 || comp == 2) return false;       // RLE4 / RLE8: not read by the reference either
-        if (comp >= 4 || comp < 0) return false;        // embedded JPEG / PNG
+        if (comp >= 4) return false;                    // embedded JPEG / PNG (a NEGATIVE field passes in the reference: treated below as "neither 0 nor 3")
         if (comp == 3 && bpp != 16 && bpp != 32) return false;
         r.skip(20);                                      // image size, resolution x / y, colours used / important
         if (hsz == 40 || hsz == 56) {
             if (hsz == 56) r.skip(16);
             if (bpp == 16 || bpp == 32) {
                 if (comp == 0) default_masks();
+                else if (comp != 3) return false;
                 else {                                   // BI_BITFIELDS: three masks behind the header
                     mr = r.u32le(); mg = r.u32le(); mb = r.u32le();
                     fixed += 12;
@@ -98,7 +99,7 @@ bool decode_bmp_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb,
             }
         } else {                                         // V4 / V5
             mr = r.u32le(); mg = r.u32le(); mb = r.u32le(); ma = r.u32le();
-            if (comp != 3) default_masks();
+            if (comp == 0) default_masks();          // (BI_BITFIELDS, and the odd negative value, keep the header's masks)
             r.skip(4 + 48);                              // colour space + endpoints / gamma
             if (hsz == 124) r.skip(16);
         }
@@ -684,12 +685,13 @@ bool decode_hdr_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb,
             o[0] = in[0] * s; o[1] = in[1] * s; o[2] = in[2] * s;
         } else o[0] = o[1] = o[2] = 0.f;
     };
+    uint8_t held[4] = {0, 0, 0, 0};
     auto flat_from = [&](size_t first) {                    // four bytes per pixel, no packing
         for (size_t i = first; i < n; i++) {
-            uint8_t q4[4] = {0, 0, 0, 0};
-            if ((size_t)(r.end - r.p) >= 4) { memcpy(q4, r.p, 4); r.p += 4; }   // (a short tail is left as it is by the reference: zeros here)
-            else r.p = r.end;
-            to_float(&f[i * 3], q4);
+            // a file that ends early: the reference's 4-byte read fails without consuming anything and the pixel it decoded last is
+            // converted again — the rest of the image repeats it
+            if ((size_t)(r.end - r.p) >= 4) { memcpy(held, r.p, 4); r.p += 4; }
+            to_float(&f[i * 3], held);
         }
     };
     if (w < 8 || w >= 32768) flat_from(0);
@@ -701,8 +703,8 @@ bool decode_hdr_impl(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb,
             if (c1 != 2 || c2 != 2 || (len & 0x80)) {
                 // not a packed scanline: the reference takes these four bytes for pixel 0 and reads the REST OF THE IMAGE flat from
                 // here, whichever scanline it was in
-                const uint8_t q4[4] = {(uint8_t)c1, (uint8_t)c2, (uint8_t)len, (uint8_t)r.u8()};
-                to_float(&f[0], q4);
+                held[0] = (uint8_t)c1; held[1] = (uint8_t)c2; held[2] = (uint8_t)len; held[3] = (uint8_t)r.u8();
+                to_float(&f[0], held);
                 flat_from(1);
                 break;
             }

@@ -87,17 +87,20 @@ bool decode_png(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
     while (p + 12 <= d.size()) {
         const uint32_t len = be32(&d[p]);
         const uint8_t * type = &d[p + 4];
+        if (!memcmp(type, "IEND", 4)) break;                                          // (whatever length it claims)
         if (p + 12 + len > d.size()) return false;
         const uint8_t * body = &d[p + 8];
         if (!memcmp(type, "IHDR", 4)) {
             if (len < 13) return false;
             w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+            if (body[10] != 0 || body[11] != 0 || interlace > 1) return false;      // compression / filter method 0 only, interlace 0 or 1
         } else if (!memcmp(type, "PLTE", 4)) {
+            if (len > 256 * 3 || len % 3) return false;
             plte.assign(body, body + len);
         } else if (!memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), body, body + len);
-        } else if (!memcmp(type, "IEND", 4)) {
-            break;
+        } else if ((type[0] & 0x20) == 0 && memcmp(type, "tRNS", 4) != 0) {
+            return false;                                                             // an unknown CRITICAL chunk (upper-case first letter)
         }
         p += 12 + len;
     }
@@ -112,14 +115,28 @@ bool decode_png(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
     default: return false;
     }
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
+    if (ctype == 3 && plte.empty()) return false;                                    // indexed colour needs its table
     const int bpp_bits = chans * depth;
     // inflate
     size_t raw_cap = 0;
     if (!interlace) raw_cap = (((size_t)w * bpp_bits + 7) / 8 + 1) * h;
     else raw_cap = (((size_t)w * bpp_bits + 7) / 8 + 8) * (h + 8) * 2;
     std::vector<uint8_t> raw(raw_cap);
-    uLongf dl = (uLongf)raw.size();
-    if (uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size()) != Z_OK) return false;
+    uLongf dl = 0;
+    {
+        // streamed inflate instead of uncompress(): what matters is that the scanlines come out — data behind them (a file whose IDAT
+        // holds more than the image needs) and a wrong Adler-32 trailer are not errors for the reference's decoder either
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) return false;
+        zs.next_in = idat.data(); zs.avail_in = (uInt)std::min<size_t>(idat.size(), 0xffffffffu);
+        zs.next_out = raw.data(); zs.avail_out = (uInt)std::min<size_t>(raw.size(), 0xffffffffu);
+        const int zr = inflate(&zs, Z_FINISH);
+        dl = zs.total_out;
+        const bool trailer_only = zr == Z_DATA_ERROR && zs.msg && strstr(zs.msg, "incorrect data check");
+        inflateEnd(&zs);
+        if (zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR && !trailer_only) return false;
+    }
 
     nx = w; ny = h;
     rgb.assign((size_t)w * h * 3, 0);

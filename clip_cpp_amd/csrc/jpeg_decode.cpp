@@ -171,12 +171,26 @@ struct Decoder {
     }
 
     // ---- block decoders ----
+    // the DC term has to fit 16 bits after scaling (both factors taken as 16-bit values, as the reference's check takes them); a predictor
+    // that would leave the int range is refused as well
+    static bool dc_fits(int dc, int scale) {
+        const int a = (int16_t)dc, b = (int16_t)scale;
+        if (b == 0 || b == -1) return true;
+        if ((a >= 0) == (b >= 0)) return a <= 32767 / b;
+        return b < 0 ? a <= -32768 / b : a >= -32768 / b;
+    }
+    static bool pred_fits(int pred, int diff) {
+        if ((pred >= 0) != (diff >= 0)) return true;
+        return pred < 0 ? pred >= INT32_MIN - diff : pred <= INT32_MAX - diff;
+    }
     bool block_baseline(int16_t * data, Component & c) {
         memset(data, 0, 64 * sizeof(int16_t));
         const int t = decode_sym(hdc[c.td]);
         if (t < 0 || t > 15) return fail("bad huffman code");
         const int diff = t ? receive_extend(t) : 0;
+        if (!pred_fits(c.dc_pred, diff)) return fail("bad DC delta");
         c.dc_pred += diff;
+        if (!dc_fits(c.dc_pred, qt[c.tq][0])) return fail("DC term out of range");
         data[0] = (int16_t)c.dc_pred;
         const Huff & ac = hac[c.ta];
         int k = 1;
@@ -200,7 +214,9 @@ struct Decoder {
             const int t = decode_sym(hdc[c.td]);
             if (t < 0 || t > 15) return fail("bad huffman code");
             const int diff = t ? receive_extend(t) : 0;
+            if (!pred_fits(c.dc_pred, diff)) return fail("bad DC delta");
             c.dc_pred += diff;
+            if (!dc_fits(c.dc_pred, 1 << al)) return fail("DC term out of range");
             data[0] = (int16_t)(c.dc_pred * (1 << al));
         } else {
             if (getbit()) data[0] = (int16_t)(data[0] + (1 << al));
@@ -271,80 +287,53 @@ struct Decoder {
     static inline uint8_t clamp8(int x) { return (uint8_t)((unsigned)x > 255 ? (x < 0 ? 0 : 255) : x); }
     static inline int fx(double v) { return (int)(v * 4096 + 0.5); }
 
-    static void idct1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int & x0, int & x1, int & x2, int & x3, int & t0, int & t1,
-                       int & t2, int & t3) {
-        int p2 = s2, p3 = s6;
-        int p1 = (p2 + p3) * fx(0.5411961);
-        t2 = p1 + p3 * fx(-1.847759065);
-        t3 = p1 + p2 * fx(0.765366865);
-        p2 = s0;
-        p3 = s4;
-        t0 = (p2 + p3) * 4096;
-        t1 = (p2 - p3) * 4096;
-        x0 = t0 + t3;
-        x3 = t0 - t3;
-        x1 = t1 + t2;
-        x2 = t1 - t2;
-        t0 = s7;
-        t1 = s5;
-        t2 = s3;
-        t3 = s1;
-        p3 = t0 + t2;
-        int p4 = t1 + t3;
-        p1 = t0 + t3;
-        p2 = t1 + t2;
-        const int p5 = (p3 + p4) * fx(1.175875602);
-        t0 = t0 * fx(0.298631336);
-        t1 = t1 * fx(2.053119869);
-        t2 = t2 * fx(3.072711026);
-        t3 = t3 * fx(1.501321110);
-        p1 = p5 + p1 * fx(-0.899976223);
-        p2 = p5 + p2 * fx(-2.562915447);
-        p3 = p3 * fx(-1.961570560);
-        p4 = p4 * fx(-0.390180644);
-        t3 += p1 + p4;
-        t2 += p2 + p3;
-        t1 += p2 + p4;
-        t0 += p1 + p3;
+    // One 1-D pass over eight 16-bit inputs.  The arithmetic is the scalar LL&M flow regrouped the way the reference's SSE2 kernel groups it
+    // (the same integers for every valid stream): the four input sums s0 +- s4, s1 + s7, s3 + s5 are formed in 16 bits and WRAP, every
+    // product and sum behind them is 32-bit (wrapping), and the eight results are shifted and SATURATED back to 16 bits.  Only corrupt
+    // streams (coefficients x quantisers beyond 16 bits) ever reach the wrap / saturation; with them the pixels still equal that decoder's.
+    static inline int sat16(int x) { return x > 32767 ? 32767 : (x < -32768 ? -32768 : x); }
+    static inline int32_t wrap_mul(int a, int b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+    static inline int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+    static inline int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+    static void idct1d(const int s[8], int32_t bias, int shift, int out[8]) {
+        const int c0541 = fx(0.5411961), cm1847 = fx(-1.847759065), c0765 = fx(0.765366865), c1175 = fx(1.175875602), cm0899 = fx(-0.899976223),
+                  cm2562 = fx(-2.562915447), cm1961 = fx(-1.961570560), c0298 = fx(0.298631336), c3072 = fx(3.072711026), cm0390 = fx(-0.390180644),
+                  c2053 = fx(2.053119869), c1501 = fx(1.501321110);
+        const int e04 = (int16_t)(s[0] + s[4]), d04 = (int16_t)(s[0] - s[4]), a17 = (int16_t)(s[1] + s[7]), a35 = (int16_t)(s[3] + s[5]);
+        // even part
+        const int32_t t2e = wrap_add(wrap_mul(s[2], c0541), wrap_mul(s[6], c0541 + cm1847));
+        const int32_t t3e = wrap_add(wrap_mul(s[2], c0541 + c0765), wrap_mul(s[6], c0541));
+        const int32_t t0e = wrap_mul(e04, 4096), t1e = wrap_mul(d04, 4096);
+        const int32_t x0 = wrap_add(t0e, t3e), x3 = wrap_sub(t0e, t3e), x1 = wrap_add(t1e, t2e), x2 = wrap_sub(t1e, t2e);
+        // odd part
+        const int32_t y0 = wrap_add(wrap_mul(s[7], cm1961 + c0298), wrap_mul(s[3], cm1961));
+        const int32_t y2 = wrap_add(wrap_mul(s[7], cm1961), wrap_mul(s[3], cm1961 + c3072));
+        const int32_t y1 = wrap_add(wrap_mul(s[5], cm0390 + c2053), wrap_mul(s[1], cm0390));
+        const int32_t y3 = wrap_add(wrap_mul(s[5], cm0390), wrap_mul(s[1], cm0390 + c1501));
+        const int32_t y4 = wrap_add(wrap_mul(a17, c1175 + cm0899), wrap_mul(a35, c1175));
+        const int32_t y5 = wrap_add(wrap_mul(a17, c1175), wrap_mul(a35, c1175 + cm2562));
+        const int32_t x4 = wrap_add(y0, y4), x5 = wrap_add(y1, y5), x6 = wrap_add(y2, y5), x7 = wrap_add(y3, y4);
+        const int32_t xe[4] = {x0, x1, x2, x3}, xo[4] = {x7, x6, x5, x4};
+        for (int k = 0; k < 4; k++) {
+            const int32_t a = wrap_add(xe[k], bias);
+            out[k] = sat16(wrap_add(a, xo[k]) >> shift);
+            out[7 - k] = sat16(wrap_sub(a, xo[k]) >> shift);
+        }
     }
 
     static void idct_block(uint8_t * out, int stride, const int16_t * d) {
         int val[64];
-        for (int i = 0; i < 8; i++) {
-            const int16_t * c = d + i;
-            int * v = val + i;
-            if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-                const int dc = c[0] * 4;
-                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
-            } else {
-                int x0, x1, x2, x3, t0, t1, t2, t3;
-                idct1d(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56], x0, x1, x2, x3, t0, t1, t2, t3);
-                x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-                v[0] = (x0 + t3) >> 10;
-                v[56] = (x0 - t3) >> 10;
-                v[8] = (x1 + t2) >> 10;
-                v[48] = (x1 - t2) >> 10;
-                v[16] = (x2 + t1) >> 10;
-                v[40] = (x2 - t1) >> 10;
-                v[24] = (x3 + t0) >> 10;
-                v[32] = (x3 - t0) >> 10;
-            }
+        for (int i = 0; i < 8; i++) {                      // columns: 2 extra bits of precision kept (>> 10 of 12)
+            const int col[8] = {d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]};
+            int o[8];
+            idct1d(col, 512, 10, o);
+            for (int k = 0; k < 8; k++) val[k * 8 + i] = o[k];
         }
-        for (int i = 0; i < 8; i++) {
-            const int * v = val + i * 8;
-            uint8_t * o = out + i * stride;
-            int x0, x1, x2, x3, t0, t1, t2, t3;
-            idct1d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x0, x1, x2, x3, t0, t1, t2, t3);
-            const int bias = 65536 + (128 << 17);
-            x0 += bias; x1 += bias; x2 += bias; x3 += bias;
-            o[0] = clamp8((x0 + t3) >> 17);
-            o[7] = clamp8((x0 - t3) >> 17);
-            o[1] = clamp8((x1 + t2) >> 17);
-            o[6] = clamp8((x1 - t2) >> 17);
-            o[2] = clamp8((x2 + t1) >> 17);
-            o[5] = clamp8((x2 - t1) >> 17);
-            o[3] = clamp8((x3 + t0) >> 17);
-            o[4] = clamp8((x3 - t0) >> 17);
+        for (int i = 0; i < 8; i++) {                      // rows: >> 17 with the rounding and the +128 level shift in the bias
+            int o[8];
+            idct1d(val + i * 8, 65536 + (128 << 17), 17, o);
+            uint8_t * q = out + i * stride;
+            for (int k = 0; k < 8; k++) q[k] = clamp8(o[k]);
         }
     }
 

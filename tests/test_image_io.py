@@ -684,3 +684,38 @@ def test_radiance_hdr_equals_reference_decoder(clip_lib, stb, tmp_path, w, h):
         same(head + one_packed_row + px[w:].tobytes() + bytes(4 * w), must_load=False)
     same(_hdr(w, h, px, rle=False).replace(b"FORMAT=32-bit_rle_rgbe", b"FORMAT=32-bit_rle_xyze"), must_load=False)
     same(_hdr(w, h, px, rle=False).replace(b"-Y ", b"+Y "), must_load=False)
+
+
+def test_out_of_spec_files_decode_like_the_reference_decoder(clip_lib, stb, tmp_path):
+    """Files a careless writer or a flipped bit produces, which the reference still decodes — to well-defined pixels: quantisation tables that
+    push the IDCT past 16 bits (its SSE2 kernel wraps / saturates there), a DC term out of range (refused), PNGs with a wrong Adler-32 or with
+    more IDAT data than the image needs or an IEND of any length, a BMP whose compression field is negative, an HDR that ends early."""
+    import zlib
+    same = lambda data, name, **kw: _same_as_reference(clip_lib, stb, tmp_path, data, name, **kw)
+    img = _photo(23, 31, seed=2)
+    for kw in (dict(), dict(progressive=True), dict(subsampling=0)):
+        for pim in (PIL.fromarray(img), PIL.fromarray(img).convert("L")):
+            s = _pil_bytes(pim, "JPEG", quality=85, **kw)
+            i = s.index(b"\xff\xdb")
+            for off in (5, 6, 20, 68):
+                for v in (0, 1, 127, 128, 200, 255):
+                    d = bytearray(s)
+                    d[i + off] = v
+                    same(bytes(d), "q.jpg", must_load=False)
+    rows = b"".join(b"\0" + bytes(img[y].tobytes()) for y in range(23))
+    good = _png(31, 23, 8, 2, rows)
+    z0 = good.index(b"IDAT") + 4
+    zlen = struct.unpack(">I", good[z0 - 8:z0 - 4])[0]
+    bad_adler = bytearray(good)
+    bad_adler[z0 + zlen - 1] ^= 0x55
+    assert np.array_equal(same(bytes(bad_adler), "a.png"), img)
+    assert np.array_equal(same(_png(31, 23, 8, 2, rows + bytes(500)), "s.png"), img)                     # surplus scanline data
+    assert np.array_equal(same(good[:-12] + struct.pack(">I", 77) + b"IEND" + b"\0\0\0\0", "e.png"), img)
+    same(good.replace(b"IDAT", b"IDAT", 1).replace(b"IEND", b"JUNK"), "u.png", must_load=False)           # unknown critical chunk
+    same(_png(31, 23, 8, 3, b"".join(b"\0" + bytes(31) for _ in range(23))), "p.png", must_load=False)   # indexed colour without PLTE
+    bmp = bytearray(_bmp(31, 23, 24, [img[y, :, ::-1].tobytes() for y in range(23)]))
+    bmp[30:34] = struct.pack("<i", -5)
+    assert np.array_equal(same(bytes(bmp), "n.bmp"), img)
+    px = _rgbe(np.exp(np.random.default_rng(1).normal(-1.0, 2.0, (5 * 6, 3))))
+    hdr = _hdr(5, 6, px, rle=False)
+    same(hdr[:-4 * 7 - 2], "short.hdr")                                                                   # the last full pixel repeats
