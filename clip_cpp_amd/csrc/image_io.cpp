@@ -100,7 +100,8 @@ bool decode_png(const std::vector<uint8_t> & d, std::vector<uint8_t> & rgb, int 
         } else if (!memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), body, body + len);
         } else if ((type[0] & 0x20) == 0 && memcmp(type, "tRNS", 4) != 0) {
-            return false;                                                             // an unknown CRITICAL chunk (upper-case first letter)
+            return false;     // an unknown CRITICAL chunk (upper-case first letter).  Apple's CgBI flavour lands here too: the reference's inflate refuses a
+                              // headerless stream that ends without spare bytes, i.e. practically every such file
         }
         p += 12 + len;
     }
