@@ -149,6 +149,9 @@ def kernel_grid_workgroups(name, shape):
     m = re.match(r"gemm8_kernel<(\d+),\d+>", name)
     if m:
         return -(-M // (32 * int(m.group(1)))) * -(-N // 256)
+    m = re.match(r"gemm32_kernel<(\d+),(\d+),\d+>", name)      # k_gemm32.hip: (64 WM) x (64 WN) tiles
+    if m:
+        return -(-M // (64 * int(m.group(1)))) * -(-N // (64 * int(m.group(2))))
     return None
 
 
@@ -580,6 +583,15 @@ def main():
     img_out = emb[:batch]
     txt_out = emb[batch:]
 
+    def share(on):
+        # the two towers of a step run concurrently on two contexts: say so (clip_amd_set_device_shared: the heuristic keeps to the kernels
+        # that share a CU); the single-tower rates below switch it off again
+        if overlap:
+            clip.set_device_shared(on)
+            clip_t.set_device_shared(on)
+
+    share(True)
+
     def local_step():
         if overlap:
             tstream.wait_stream(stream)          # fork: the text tower of this step starts with the vision tower
@@ -617,7 +629,7 @@ def main():
     value = per_step_units * steps / dt
     assert bool(torch.isfinite(emb).all()), "non-finite embeddings"
 
-    # separate image-only / text-only rates (rank-local, informative)
+    # separate image-only / text-only rates (rank-local, informative): one tower at a time = the device is not shared
     def rate(fn, units):
         fn(); torch.cuda.synchronize()
         n = max(3, steps // 2)
@@ -629,8 +641,10 @@ def main():
 
     img_rate = txt_rate = 0.0
     if not args.no_rates:
+        share(False)
         img_rate = rate(lambda: clip.encode_images_device(imgs.data_ptr(), batch, img_out.data_ptr(), True), batch)
         txt_rate = rate(lambda: clip.encode_texts_device(d_ids.data_ptr(), offsets, txt_out.data_ptr(), True), n_texts) if n_texts else 0.0
+        share(True)       # (the per-kernel pass below times the kernels of the STEP: same heuristic)
 
     # whole-step roofline: algorithmic work of one GPU's step against the measured step time
     fl_step, by_step = algorithmic_work(vc, tc, cfg["ftype"], batch, [len(t) for t in texts])

@@ -60,13 +60,13 @@ API_SYMBOLS = [
 ]
 AMD_SYMBOLS = [
     "clip_amd_device_count", "clip_amd_model_load", "clip_amd_model_load_multi", "clip_amd_ctx_device_count", "clip_amd_weights_from_cache", "clip_amd_shard_bounds",
-    "clip_amd_gathered_embeddings", "clip_amd_ctx_device", "clip_amd_set_stream", "clip_amd_image_batch_encode_device_multi",
+    "clip_amd_gathered_embeddings", "clip_amd_ctx_device", "clip_amd_set_stream", "clip_amd_set_device_shared", "clip_amd_image_batch_encode_device_multi",
     "clip_amd_text_batch_encode_device_multi", "clip_amd_encode_pair_device_multi",
     "clip_amd_image_batch_encode_device", "clip_text_batch_encode", "clip_amd_text_batch_encode_device",
     "clip_amd_image_batch_preprocess_device", "clip_amd_image_batch_encode_u8",
     "clip_amd_zero_shot_score_device", "clip_amd_zero_shot_label_images",
     "clip_amd_synchronize", "clip_amd_profile_enable", "clip_amd_profile_read", "clip_amd_profile_report",
-    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_gemm_tile", "clip_amd_test_skinny", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
+    "clip_amd_test_gemm", "clip_amd_test_gemm_ex", "clip_amd_test_gemm_tile", "clip_amd_test_gemm_tile_ex", "clip_amd_test_skinny", "clip_amd_test_layernorm", "clip_amd_test_attention", "clip_amd_bench_gemm",
 ]
 
 _lib = None
@@ -140,6 +140,8 @@ def lib():
     L.clip_amd_ctx_device.restype = i32
     L.clip_amd_ctx_device.argtypes = [vp]
     L.clip_amd_set_stream.argtypes = [vp, vp]
+    L.clip_amd_set_device_shared.restype = None
+    L.clip_amd_set_device_shared.argtypes = [vp, i32]
     L.clip_amd_synchronize.argtypes = [vp]
     L.clip_amd_image_batch_encode_device.restype = C.c_bool
     L.clip_amd_image_batch_encode_device.argtypes = [vp, vp, i32, vp, C.c_bool]
@@ -171,6 +173,8 @@ def lib():
                                        i32, i32, i32, i32, i32, C.c_float, f32p, f32p]
     L.clip_amd_test_gemm_tile.restype = i32
     L.clip_amd_test_gemm_tile.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32]
+    L.clip_amd_test_gemm_tile_ex.restype = i32
+    L.clip_amd_test_gemm_tile_ex.argtypes = [C.c_int64, C.c_int64, C.c_int64, i32, i32]
     L.clip_amd_test_skinny.restype = i32
     L.clip_amd_test_skinny.argtypes = [i32, vp, C.c_int64, C.c_int64, f32p, C.c_int64, f32p, f32p, f32p, f32p, C.c_float, f32p, i32, i32, C.c_float, f32p]
     L.clip_amd_bench_gemm.restype = C.c_float
@@ -391,6 +395,10 @@ class Clip:
 
     def set_stream(self, stream_handle):
         lib().clip_amd_set_stream(self.ctx, C.c_void_p(stream_handle))
+
+    def set_device_shared(self, shared=True):
+        """the caller runs other work on this device concurrently (clip_amd_set_device_shared: the other tower of a two-tower step)."""
+        lib().clip_amd_set_device_shared(self.ctx, 1 if shared else 0)
 
     def synchronize(self):
         lib().clip_amd_synchronize(self.ctx)

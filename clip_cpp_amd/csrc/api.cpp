@@ -71,6 +71,10 @@ int clip_amd_device_count(void) {
     return n;
 }
 int clip_amd_ctx_device(const struct clip_ctx * ctx) { return ctx ? ctx->device : -1; }
+void clip_amd_set_device_shared(struct clip_ctx * ctx, int shared) {
+    if (ctx) ctx->device_shared = shared != 0;
+}
+
 void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream) {
     if (!ctx || ctx->device < 0) return;
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -666,6 +670,10 @@ int clip_amd_profile_read(struct clip_ctx * ctx, float * ms, int64_t * launches,
 int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised) {
     const int Kpad = (int)((K + 63) / 64 * 64);
     return gemm_tile_for((int)M, (int)N, Kpad, quantised != 0);
+}
+int clip_amd_test_gemm_tile_ex(int64_t M, int64_t N, int64_t K, int quantised, int shared_device) {
+    const int Kpad = (int)((K + 63) / 64 * 64);
+    return gemm_tile_for((int)M, (int)N, Kpad, quantised != 0, shared_device != 0);
 }
 
 // Extended form: qcols / qscale (EPI_F16 Q-scale path, clip.cpp:1363) and epilogue 5 = EPI_PATCH_F32 (patch embedding:

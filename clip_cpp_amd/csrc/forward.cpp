@@ -115,15 +115,19 @@ double weight_bytes(const DevWeight & W) {
     return 0;
 }
 
+// the device carries other work next to this context's: declared by the caller, or this context is / has a busy sibling (two-tower pair calls)
+bool device_shared(const clip_ctx * ctx) { return ctx->device_shared || ctx->sibling_busy || ctx->owner != nullptr; }
+
 void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
     GemmParams p = p0;
+    p.shared_device = device_shared(ctx);
     p.sk_ws = ctx->sk_ws; p.sk_ws_floats = ctx->sk_ws_floats; p.sk_cnt = ctx->sk_cnt; p.sk_cnt_n = ctx->sk_cnt_n;
     if (!ctx->profiling) {
         launch_gemm(p, epi, 0, ctx->stream);
         return;
     }
     const int wt = p.w16_pre ? (int)W_F16 : p.W.wtype;       // a dequantised panel is multiplied as an f16 weight (launch_gemm)
-    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, wt != W_F16);
+    const int tile = gemm_tile_for(p.M, p.W.N, p.W.Kpad, wt != W_F16, p.shared_device);
     const bool panel = gemm_tile_uses_panel(tile) && wt == W_F16;
     const double fl = 2.0 * p.M * (double)p.W.N * p.W.K;
     const double wb = wt == W_F16 ? (double)p.W.N * p.W.K * 2 : weight_bytes(p.W);
@@ -132,6 +136,7 @@ void gemm(clip_ctx * ctx, const char * what, const GemmParams & p0, int epi) {
     // tag = kernel instantiation (matches the rocprofv3 kernel names gemm_dma_kernel<WT, BM, BN, EPI> / gemm8_kernel<TM, EPI>) + role
     char fam[96];
     if (wt == W_F32) snprintf(fam, sizeof fam, "gemm_f32_kernel<%d>/%s", epi, what);      // f32 file: exact-f32 MFMA (k_gemm_f32.hip)
+    else if (panel && tile % 1000 == 261 && (epi == EPI_F16 || epi == EPI_GELU_F16 || epi == EPI_QGELU_F16)) snprintf(fam, sizeof fam, "gemm32_kernel<%d,4,%d>/%s", tile / 1000 == 320 ? 5 : 4, epi, what);
     else if (panel && tile % 1000 >= 259) snprintf(fam, sizeof fam, "gemm4_kernel<%d>/%s", epi, what);   // (+ a short second launch for the rows past the whole rounds)
     else if (panel) snprintf(fam, sizeof fam, "gemm8_kernel<%d,%d>/%s", tile / 32000, epi, what);
     else if (gemm_tile_is_ring(tile)) snprintf(fam, sizeof fam, "gemm_ring_kernel<%d,%d,4,%d,%d>/%s", wt, tile % 1000, tile % 1000 >= 128 ? 4 : 2, epi, what);
@@ -166,7 +171,10 @@ LayerPanels dequant_layer(clip_ctx * ctx, const DevLayer & l, int rows, const ha
     size_t need = 0;
     bool todo[4];
     for (int i = 0; i < 4; i++) {
-        if (res && res[i]) { *slot[i] = res[i]; todo[i] = false; continue; }       // kept from the first large batch: nothing to dequantise
+        // kept from the first large batch: nothing to dequantise.  (A q/k/v or FFN-up panel exists for the 32 x 32 x 16 kernel only: where the
+        // heuristic does not pick that kernel — device shared with the other tower, another row count — the fused kernels multiply the quantised planes)
+        const bool for32 = i == 0 || i == 2;
+        if (res && res[i] && (!for32 || gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, false, device_shared(ctx)) % 1000 == 261)) { *slot[i] = res[i]; todo[i] = false; continue; }
         todo[i] = ws[i]->wtype != W_F16 && ws[i]->wtype != W_F32 && gemm_tile_uses_panel(gemm_tile_for(rows, ws[i]->N, ws[i]->Kpad, true));
         if (todo[i]) need += (size_t)ws[i]->Npad * ws[i]->Kpad;
     }
@@ -393,7 +401,7 @@ bool run_layers_fold(clip_ctx * ctx, const DevTower & tw, int rows, int h, int n
         p.xg_mu = mu_cur;
         p.xg_out = xn; p.ldxg = h; p.xg_gamma = gamma_next; p.stats_out = stats; p.stats_stride = stats_stride;
         const bool quant = !p.w16_pre && p.W.wtype != W_F16;
-        slotw = gemm_fold_slotw_for(p.M, p.W.N, p.W.Kpad, quant);
+        slotw = gemm_fold_slotw_for(p.M, p.W.N, p.W.Kpad, quant, device_shared(ctx));
         slots = h / slotw;
     };
     for (size_t li = 0; li < tw.layers.size(); li++) {
@@ -478,6 +486,9 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
     const DevLayer & l0 = tw.layers[0];
     unsigned want = 0;
     if (l0.ff2.wtype != W_F16 && l0.ff2.wtype != W_F32 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
+    // round 6: q/k/v and FFN-up where the 32 x 32 x 16 kernel (k_gemm32.hip: fp16 x fp16) takes the shape (ViT-B/32 at batch 256: 99 MB per tower)
+    if (l0.qkv.wtype != W_F16 && l0.qkv.wtype != W_F32 && gemm_tile_for(rows, l0.qkv.N, l0.qkv.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 1u;
+    if (l0.ff1.wtype != W_F16 && l0.ff1.wtype != W_F32 && gemm_tile_for(rows, l0.ff1.N, l0.ff1.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 4u;
     if (!want) return nullptr;
     auto & tab = ctx->res_panels[which];
     if ((ctx->res_panel_mask[which] & want) == want && tab.size() == 4 * tw.layers.size()) return tab.data();
@@ -517,11 +528,12 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
 // — measured r03cfg, ViT-L/14 f16 batch 256: FFN-down +128 us, out-projection +106 us, FFN-up +61 us, q/k/v +31 us per launch against
 // 2 x 82 us of LayerNorm launches saved per layer: 4374 img/s folded vs 4690 unfolded — so a tower whose layers touch those kernels at
 // this row count keeps the LayerNorm launches.
-bool fold_pays(const DevTower & tw, int rows) {
+bool fold_pays(const DevTower & tw, int rows, bool shared) {
     if (tw.layers.empty()) return false;
     const DevLayer & l = tw.layers[0];
     for (const DevWeight * w : {&l.qkv, &l.o, &l.ff1, &l.ff2})
-        if (gemm_tile_uses_panel(gemm_tile_for(rows, w->N, w->Kpad, w->wtype != W_F16))) return false;
+        if (gemm_tile_uses_panel(gemm_tile_for(rows, w->N, w->Kpad, w->wtype != W_F16, shared)) &&
+            gemm_tile_for(rows, w->N, w->Kpad, w->wtype != W_F16, shared) % 1000 != 261) return false;      // (k_gemm32.hip carries the consumer half at no visible cost)
     return true;
 }
 
@@ -855,7 +867,7 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
     const int Bc = st.Bc, rows = Bc * T;
     float * x = st.x;
     const bool skinny = layers_fit_skinny(V, rows, h, ff);
-    const bool fold = ctx->ln_fold && !V.layers.empty() && (ctx->ln_fold_force || fold_pays(V, rows));
+    const bool fold = ctx->ln_fold && !V.layers.empty() && (ctx->ln_fold_force || fold_pays(V, rows, device_shared(ctx)));
     {
         ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * (fold ? 10 : 8));
         if (fold)   // class-token rows (:1315-1331) + pre-LN (:1334-1339) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
@@ -1046,7 +1058,7 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
     }
     auto launch_all = [&]() -> bool {
         const bool skinny = layers_fit_skinny(Tw, rows, h, ff);
-        const bool fold = ctx->ln_fold && !Tw.layers.empty() && (ctx->ln_fold_force || fold_pays(Tw, rows));
+        const bool fold = ctx->ln_fold && !Tw.layers.empty() && (ctx->ln_fold_force || fold_pays(Tw, rows, device_shared(ctx)));
         const bool prune = ctx->prune_last && !skinny && !Tw.layers.empty() && rows > n_texts;
         if (fold)   // embedding (:1059-1061) + entry of the folded chain: xn = fp16(x ln1_w[0]), whole-row statistics
             launch_text_embed(d_ids + h_offsets[0], seq, n_texts, rows, Tw.tok_raw, Tw.tok_type, Tw.pos, h, x, s, Tw.layers[0].ln1_w, xn, h, stats, ctx->ln_fold_centre ? mu : nullptr);

@@ -449,7 +449,7 @@ int tile_override(int M, int N, int Kpad) {
     return 0;
 }
 
-int pick_tile(int M, int N, int Kpad, bool quantised) {
+int pick_tile(int M, int N, int Kpad, bool quantised, bool shared = false) {
     auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (const int ov = tile_override(M, N, Kpad)) return ov;
     if (M <= 64) return 64064;
@@ -486,6 +486,22 @@ int pick_tile(int M, int N, int Kpad, bool quantised) {
     // l14.down 542 vs 579 / 607, l14.up 645 vs 652 / 705; at 32896 rows (batch 128): qkv 223 vs 238 / 241, down 287 vs 321 / 333,
     // out 110 vs 117 / 107, up 333 vs 332 / 360.  From two rounds of tiles up.
     if (M >= 32768 && wgs(256, 256) >= 2 * 256) return 256260;
+    // Round 6 — the wide fp16-output GEMMs of a ViT-B/32-class batch (q/k/v: N = 3 K, FFN-up: N = 4 K; 8192-32767 rows) on fp16 weights
+    // (f16 files, or a resident panel of a block-quantised weight: forward.cpp resident_panels asks with quantised = false): the
+    // 32 x 32 x 16 kernel of k_gemm32.hip, one workgroup per CU, on whichever of its two tiles (256 / 320 x 256) wastes less of its last
+    // round of 256 — and only where at least 80 % of the rounds' slots hold a tile (text FFN-up 10290 x 2048: 328 / 264 tiles = 64 / 52 %:
+    // the two-per-CU kernel below stays ahead there).  Other epilogues at such a shape fall through to the 16 x 16 x 32 kernels (launch_gemm).
+    // ONLY when the device is not shared (GemmParams::shared_device): a tower alone gains 2.3 % (vision) / 3.4 % (text) from it, but with the
+    // other tower on a second stream the two-tower step LOSES 0.4-2.7 % (profiles/r06_experiments.txt section 3): a 135-150 KB workgroup has
+    // its CU to itself, so its prologue and epilogue (45 % of its tile time) idle the matrix pipe, where two 72-80 KB workgroups of either
+    // tower fill each other's.  At M >= 32768 (ViT-L/14) it is level with k_gemm4.hip (0.32-0.34 of the MFMA peak both) and not used.
+    if (!shared && !quantised && M >= 8192 && N >= 2 * Kpad && (N & 63) == 0 && Kpad >= 128) {
+        const int t4 = wgs(256, 256), t5 = wgs(320, 256);
+        const int c4 = ((t4 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 320;     // rounds x rows per tile ~ time
+        const bool five = c5 < c4;
+        const int t = five ? t5 : t4;
+        if ((float)t >= 0.8f * (float)(((t + 255) / 256) * 256)) return five ? 320261 : 256261;
+    }
     {
         const int t8 = wgs(160, 256);
         const float rounds = (float)t8 / 256.f;
@@ -529,7 +545,7 @@ void launch_gemm_wt3(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt4(const GemmParams &, int, int, hipStream_t);
 void launch_gemm_wt5(const GemmParams &, int, int, hipStream_t);
 
-int gemm_tile_for(int M, int N, int Kpad, bool quantised) { return pick_tile(M, N, Kpad, quantised); }
+int gemm_tile_for(int M, int N, int Kpad, bool quantised, bool shared_device) { return pick_tile(M, N, Kpad, quantised, shared_device); }
 
 // LayerNorm fold: columns per statistics slot written by the residual epilogue of the kernel behind a tile code (fold_slotw<TN>() of
 // gemm_common.h: 64 where a wave spans >= 64 columns — the BN = 128 tiles of this file, k_gemm8.hip, k_gemm4.hip —, else 32)
@@ -544,7 +560,7 @@ static int fold_rest_tile(int M, int N, int Kpad, bool quantised) {
     const int t = pick_tile(M, N, Kpad, quantised);
     return gemm_fold_slotw(t) == 64 && t % 1000 != 258 && t % 1000 != 260 ? t : 64128;
 }
-int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised) { return gemm_fold_slotw(pick_tile(M, N, Kpad, quantised)); }
+int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised, bool shared_device) { return gemm_fold_slotw(pick_tile(M, N, Kpad, quantised, shared_device)); }
 
 // Split-K factor for a BM = 64 tile grid (small-M problems: batch 1 / 32, single texts), fitted with
 // scripts/gemm_bench.py (profiles/r01_gemm_splitk.txt): a K-step costs ~0.5 us of serial latency, the fix-up ~3 us, so
@@ -581,7 +597,7 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         p.W.wtype = W_F16;
         p.W.w16 = p.w16_pre;
     }
-    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16);
+    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16, p.shared_device);
     if (tile % 1000 == 258 || tile % 1000 == 260) {
         // 256 x 256 tiles in whole rounds: one workgroup per CU means a launch costs ceil(tiles / 256) rounds, and ViT-L/14's
         // 65792 rows are 257 tile rows — one past a round boundary for every N.  The leading tile rows that fill whole rounds go to
@@ -624,6 +640,13 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         if (panel) {
             p.W.wtype = W_F16;
             p.W.w16 = panel;
+            if (tile % 1000 == 261 ) {   // k_gemm32.hip: the fp16-output GEMMs (q/k/v, FFN-up) on 32 x 32 x 16 fragments
+                if (gemm32_supported(p, epilogue)) {
+                    launch_gemm32(p, epilogue, tile / 1000 == 320 ? 5 : 4, stream);
+                    return;
+                }
+                tile = 256259;                         // another epilogue / an odd shape: the 16 x 16 x 32 form of the same tile
+            }
             if (tile % 1000 == 259 && !p.xg_out) {      // (consumer half of the LayerNorm fold: in the kernel since round 5)
                 launch_gemm4(p, epilogue, stream);
                 return;

@@ -114,18 +114,22 @@ struct GemmParams {
     const float * xg_mu = nullptr;         // producer: [M] offsets the new operand is centred on
     const float * ln_mu = nullptr;         // consumer: [M] offsets A was centred on
     float * mu_out = nullptr;              // consumer: [M], the workgroups of the first column tile leave this LayerNorm's row means here
+    // the caller runs other work on this device at the same time (the other tower of a two-tower step on a second stream): the heuristic then
+    // keeps to the kernels that share a CU (two workgroups of <= 80 KB LDS) — see pick_tile in k_gemm.hip, round 6
+    bool shared_device = false;
 };
 
 // tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64 / 65;
 // BM = 65: the ring kernel of k_gemm_ring.hip on 64-row tiles, BN in {64,128};
 // BN = 256 with BM in {96,128,160}: the 8-wave large-M kernel of k_gemm8.hip)
 void launch_gemm(const GemmParams & p, int epilogue, int tile, hipStream_t stream);
-int gemm_tile_for(int M, int N, int Kpad, bool quantised);   // the tile (BM*1000+BN) the heuristic picks for this shape
+int gemm_tile_for(int M, int N, int Kpad, bool quantised, bool shared_device = false);   // the tile (BM*1000+BN) the heuristic picks for this shape
 // the shape runs on a large-M kernel that multiplies an fp16 W panel (k_gemm8.hip / k_gemm4.hip).  BN codes: 256 plain 8-wave tile
 // (BM 96 / 128 / 160 / 256), 258 the 8-wave 256 x 256 tile on the rows that fill whole rounds of 256 workgroups + a second launch for the
 // rest, 259 the 4-wave 256 x 256 tile (k_gemm4.hip), 260 = 259 with the whole-rounds split
 inline bool gemm_tile_is_ring(int tile) { return (tile % 1000000) / 1000 == 65; }   // k_gemm_ring.hip (BM code 65)
-inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return !gemm_tile_is_ring(tile) && (bn == 256 || (bn >= 258 && bn <= 260)); }
+// 261: the 32 x 32 x 16 kernel of k_gemm32.hip (fp16-output epilogues): 256261 / 320261 = 256 / 320 x 256 tiles, one workgroup per CU
+inline bool gemm_tile_uses_panel(int tile) { const int bn = tile % 1000; return !gemm_tile_is_ring(tile) && (bn == 256 || (bn >= 258 && bn <= 261)); }
 
 // k_gemm_ring.hip: mid-M GEMM (64 activation rows x bn weight rows per workgroup, bn in {64, 128}; a 3-4 stage LDS ring of K-tiles
 // filled by LDS-DMA only, block-quantised weights staged raw and dequantised per MFMA fragment; split-K as k_gemm.hip: p.ksplit).
@@ -138,6 +142,9 @@ void launch_gemm8(const GemmParams & p, int epilogue, int tm, hipStream_t stream
 void launch_gemm_f32(const GemmParams & p, int epilogue, hipStream_t stream);
 // k_gemm4.hip: 4 waves x (128 x 128) on 256 x 256 tiles, accumulators in AGPRs, fp16 x fp16 (p.W.w16 = [Npad][Kpad] panel)
 void launch_gemm4(const GemmParams & p, int epilogue, hipStream_t stream);
+// k_gemm32.hip: 4 waves x ((32 wm) x 128) of v_mfma_f32_32x32x16_f16 on (64 wm) x 256 tiles, wm in {4, 5}; fp16-output epilogues on an fp16 panel
+bool gemm32_supported(const GemmParams & p, int epilogue);
+void launch_gemm32(const GemmParams & p, int epilogue, int form, hipStream_t stream);   // form: 4 = 256 x 256, 5 = 320 x 256
 // dequantise n block-quantised weights into fp16 [Npad][Kpad] panels (one launch per run of equal weight type, <= 4 weights each)
 struct DequantJobs { DevWeight W[4]; half_t * out[4]; int blk_end[4]; int n = 0; };
 void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, hipStream_t stream);
@@ -146,7 +153,7 @@ void launch_dequant(const DevWeight * const * ws, half_t * const * outs, int n, 
 // 32 for the ring kernel and the BN = 64 tiles whose waves span 32 columns), and the same for the tile launch_gemm's heuristic picks
 // for a shape in fold mode (the rows past the whole rounds of a split launch are then kept on a 64-column kernel).
 int gemm_fold_slotw(int tile);
-int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised);
+int gemm_fold_slotw_for(int M, int N, int Kpad, bool quantised, bool shared_device = false);
 // k_fold.hip (once per model load): c[n] = sum_k gamma[k] W[n][k], b_out[n] = sum_k beta[k] W[n][k] + bias[n], W as the GEMMs dequantise it
 void launch_fold_vectors(const DevWeight & W, const float * gamma, const float * beta, const float * bias, float * c_out, float * b_out,
                          hipStream_t stream);

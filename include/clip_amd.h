@@ -75,6 +75,13 @@ int clip_amd_ctx_device(const struct clip_ctx * ctx);
  * (or free it) BEFORE destroying a stream it was bound to. */
 void clip_amd_set_stream(struct clip_ctx * ctx, void * hip_stream);
 
+/* Tell the context that its device carries other work at the same time (shared != 0) — typically the other tower of a two-tower step
+ * on a second context / stream.  The GEMM heuristic then keeps to kernels that share a compute unit (two workgroups per CU); with
+ * shared == 0 (the default: one encoder call at a time, as every reference caller does) the wide q/k/v and FFN-up GEMMs of a large batch
+ * run on kernels that take a whole CU each (k_gemm32.hip).  Results agree within fp16 output rounding either way.  The two-tower
+ * multi-GPU entry point (clip_amd_encode_pair_device_multi) knows by itself. */
+void clip_amd_set_device_shared(struct clip_ctx * ctx, int shared);
+
 /* Device-resident form of clip_image_batch_encode (reference clip.cpp:1247-1523):
  * d_imgs  : B x [S,S,3] float32 interleaved RGB, already preprocessed, in HBM
  * d_out   : B x projection_dim float32 in HBM
@@ -159,6 +166,7 @@ int clip_amd_test_lnfold(int type, const void * w1_raw, int64_t h, int64_t K1, c
 /* The tile the heuristic of launch_gemm picks for an [M][K] x [N][K]^T problem (pure host arithmetic, no device needed):
  * BM * 1000 + BN; BM = 65: the mid-M ring kernel on 64-row tiles (k_gemm_ring.hip), BN = 256 / 258-260: the large-M panel kernels. */
 int clip_amd_test_gemm_tile(int64_t M, int64_t N, int64_t K, int quantised);
+int clip_amd_test_gemm_tile_ex(int64_t M, int64_t N, int64_t K, int quantised, int shared_device);   /* ... with clip_amd_set_device_shared's flag */
 /* Average device time (microseconds, HIP events) of one GEMM shape through the production kernel on random
  * weights of ggml type `type`; < 0 on error.  Used by scripts/gemm_bench.py for kernel A/B work. */
 float clip_amd_bench_gemm(int type, int64_t N, int64_t K, int64_t M, int epilogue, int tile, int iters);

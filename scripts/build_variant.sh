@@ -17,6 +17,7 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-a
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm.hip -o $V/k_gemm.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm8.hip -o $V/k_gemm8.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm4.hip -o $V/k_gemm4.hip.o &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm32.hip -o $V/k_gemm32.hip.o &
 wait
 OBJS=$(ls $B/*.o | grep -v 'k_gemm')
 hipcc --offload-arch=gfx950 -shared -fPIC -o clip_cpp_amd/variants/libclip_$NAME.so $OBJS $V/*.o -lz -lpthread -ldl

@@ -353,12 +353,26 @@ def test_resident_ffn_down_panels_do_not_change_a_bit(gpu, fixture_cache, monkey
     c0.close()
     monkeypatch.delenv("CLIP_AMD_RESIDENT_PANELS", raising=False)
     c1 = gpu.Clip(p, device=0)
+    c1.set_device_shared(True)       # the kernels of the two-tower step: only FFN-down runs on a panel (the panel-less run above is the same either way)
     c1.profile(True)
     first = run(c1)
     rep = c1.profile_report(reset=True)
     c1.profile(False)
     assert any(k.startswith("gemm8_kernel") and "ffn_down" in k for k in rep), sorted(rep)      # the panel kernel carries FFN-down
+    assert not any(k.startswith("gemm32_kernel") for k in rep), sorted(rep)
     assert np.array_equal(first, want) and np.array_equal(run(c1), want)
+    # round 6: alone on the device, q/k/v and FFN-up also get resident panels and run on the 32 x 32 x 16 kernel (k_gemm32.hip): another k order
+    # inside the MFMA -> the embeddings agree to f32 rounding of the sums, not bit for bit; back on a shared device the bits return
+    c1.set_device_shared(False)
+    c1.profile(True)
+    alone = run(c1)
+    rep = c1.profile_report(reset=True)
+    c1.profile(False)
+    assert any(k.startswith("gemm32_kernel<4,4,1>") and "qkv" in k for k in rep) and any(k.startswith("gemm32_kernel<5,4,") and "ffn_up" in k for k in rep), sorted(rep)
+    assert float(one_minus_cos(alone, want).max()) <= 1e-6, float(one_minus_cos(alone, want).max())
+    assert np.array_equal(run(c1), alone)                                      # deterministic
+    c1.set_device_shared(True)
+    assert np.array_equal(run(c1), want)
     c1.close()
 
 

@@ -443,7 +443,7 @@ def test_gemm_tile_heuristic_covers_the_model_shapes(clip_lib):
     in the obvious sense (no ring tiles for one image's rows or for batch 256)."""
     L = clip_lib.lib()
     tile = lambda M, N, K, q=1: L.clip_amd_test_gemm_tile(M, N, K, q)
-    known = {64064, 64128, 128064, 128128, 160128, 192128, 65064, 65128, 160256, 256260}
+    known = {64064, 64128, 128064, 128128, 160128, 192128, 65064, 65128, 160256, 256260, 256261, 320261}
     models = {"b32": (50, 768, 3072), "b32t": (40, 512, 2048), "l14": (257, 1024, 4096), "l14t": (40, 768, 3072), "h14": (257, 1280, 5120)}
     for name, (T, h, ff) in models.items():
         for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 1024):
@@ -451,6 +451,15 @@ def test_gemm_tile_heuristic_covers_the_model_shapes(clip_lib):
                 for q in (0, 1):
                     t = tile(B * T, N, K, q)
                     assert t in known, (name, B, N, K, q, t)
+                    if q == 1:
+                        assert t % 1000 != 261, (name, B, N, K, t)       # the 32 x 32 x 16 kernel multiplies fp16 weights only (f16 file or resident panel)
+                    assert L.clip_amd_test_gemm_tile_ex(B * T, N, K, q, 1) % 1000 != 261       # ... and never on a shared device
+    # round 6: q/k/v and FFN-up of a ViT-B/32-class batch alone on the device -> k_gemm32.hip, on the tile that fills its last round; not the narrow-round shapes
+    assert tile(12800, 2304, 768, 0) == 256261 and tile(12800, 3072, 768, 0) == 320261 and tile(10290, 1536, 512, 0) == 256261
+    assert tile(10290, 2048, 512, 0) % 1000 != 261 and tile(12800, 768, 768, 0) % 1000 != 261 and tile(12800, 768, 3072, 0) % 1000 != 261
+    assert tile(1600, 2304, 768, 0) % 1000 != 261 and tile(65792, 3072, 1024, 0) == 256260
+    for (M, N, K) in ((12800, 2304, 768), (12800, 3072, 768), (10290, 1536, 512)):
+        assert L.clip_amd_test_gemm_tile_ex(M, N, K, 0, 1) == tile(M, N, K, 1) or L.clip_amd_test_gemm_tile_ex(M, N, K, 0, 1) // 1000 in (128, 160, 192)
     # <= 64 rows: the two-buffer 64 x 64 tile (the layers themselves run on k_skinny.hip there)
     assert tile(50, 768, 768) == 64064 and tile(13, 512, 2048) == 64064
     # mid-M: the ring kernel where the sweep has it ahead ...
