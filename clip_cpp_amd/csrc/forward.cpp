@@ -744,10 +744,12 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
     if (!check_device(ctx, "clip_image_batch_encode")) return false;
     if (!ctx->graphs_enabled || ctx->profiling || B <= 0 || B > 32 || !ctx->has_vision_encoder || guard_mode())
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);   // big batches are GPU-bound: no graph needed
-    // (looked up again after every vision_forward_launch: growing a sibling's workspace drops this context's graphs — ensure_workspace)
+    // (looked up again after every vision_forward_launch: growing a sibling's workspace drops this context's graphs — ensure_workspace).
+    // The sibling's state is part of the key: the split decision differs with it, so each form has its own entry — first sighting
+    // eager, second captured — and a caller that alternates pair calls and plain calls still reaches its captures.
     auto find = [&]() -> clip_ctx::GraphEntry * {
         for (auto & g : ctx->vgraphs)
-            if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize && g.in_f16 == ctx->input_f16) return &g;
+            if (g.B == B && g.in == d_imgs && g.out == d_out && g.norm == normalize && g.in_f16 == ctx->input_f16 && g.busy_seen == ctx->sibling_busy) return &g;
         return nullptr;
     };
     clip_ctx::GraphEntry * e = find();
@@ -760,12 +762,6 @@ bool vision_forward_device(clip_ctx * ctx, const float * d_imgs, int B, float * 
     if (!e) {   // first sighting: run eagerly (allocates the workspace, sets kernel attributes)
         if (ctx->vgraphs.size() >= 16) drop_graphs(ctx);
         ctx->vgraphs.push_back({B, d_imgs, d_out, normalize, ctx->input_f16, 1, nullptr, nullptr, false, ctx->sibling_busy});
-        return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
-    }
-    if (e->busy_seen != ctx->sibling_busy) {
-        // the eager sighting took the other split decision (the sibling was busy then and is free now, or the reverse): once more eagerly, so
-        // that the form about to be captured has run — and sized every workspace it touches — outside a capture
-        e->busy_seen = ctx->sibling_busy;
         return vision_forward_launch(ctx, d_imgs, B, d_out, normalize);
     }
     // second sighting: capture

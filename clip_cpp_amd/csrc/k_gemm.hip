@@ -40,6 +40,10 @@
 
 #include "gemm_common.h"
 
+#ifndef CLIPAMD_TEST_HOOKS
+#define CLIPAMD_TEST_HOOKS 1
+#endif
+
 namespace clipamd {
 
 namespace {
@@ -432,6 +436,10 @@ void launch_epi(const GemmParams & p, int epi, int tile, hipStream_t stream) {
 // CLIP_AMD_TILE_OVERRIDE="M,N,K,tile[;M,N,K,tile...]" (tuning aid; K = 0 matches any depth): the heuristic's answer for the listed problem
 // sizes, so that a tile can be A/B-ed INSIDE the layer chain (isolated GEMM timings over-state a tile's worth there: profiles/r05_experiments.txt section 3)
 int tile_override(int M, int N, int Kpad) {
+#if !CLIPAMD_TEST_HOOKS
+    (void)M; (void)N; (void)Kpad;
+    return 0;           // (a tuning aid: compiled out of `make hooks=0` builds together with the kernel test hooks)
+#else
     struct Ov { int M, N, K, tile; };
     static const std::vector<Ov> ovs = [] {
         std::vector<Ov> v;
@@ -447,6 +455,7 @@ int tile_override(int M, int N, int Kpad) {
     }();
     for (const Ov & o : ovs) if (o.M == M && o.N == N && (o.K == 0 || o.K == Kpad)) return o.tile;
     return 0;
+#endif
 }
 
 int pick_tile(int M, int N, int Kpad, bool quantised, bool shared = false) {

@@ -2,26 +2,30 @@
 //
 //   out[M][N] (fp16) = epilogue( X[M][K] (fp16) · W16[N][K]^T (fp16 panel) + bias )          M >= ~8000 rows, K >= 128
 //
-// Why another kernel (round 6; profiles/r05_experiments.txt section 2 is the diagnosis this answers): every other GEMM in the tree issues
-// v_mfma_f32_16x16x32_f16, and their K loops are bound by the NON-MFMA instruction stream of a wave (LDS-DMA issue, fragment reads, waits)
-// — "the kernel without its MFMAs still takes 58 us, the MFMAs alone 34".  This kernel is built around that finding:
-//   * 32 x 32 x 16 fragments: half the MFMA instructions per FLOP, each 8 passes (32 cycles on its SIMD) — a wave's in-order stream has
-//     ~5 issue slots under every MFMA, and a K-tile needs (per MFMA) 0.5 fragment reads + 0.25 LDS-DMA pieces: everything else hides;
-//   * four waves, one per SIMD, each a (WM x 32) x 128 sub-tile of a (64 WM) x 256 workgroup tile, WM in {4, 5}: 256 / 320 accumulator
+// Why another kernel (round 6; profiles/r06_experiments.txt): every other GEMM in the tree issues v_mfma_f32_16x16x32_f16 and spends most of
+// its issue slots on the non-MFMA stream of a K step.  This one is built on the 32 x 32 x 16 instruction (half the MFMA instructions per
+// FLOP, 32 cycles each on its SIMD: ~5 issue slots under every MFMA, 0.5 fragment reads + 0.25 LDS-DMA requests per MFMA to fill them):
+//   * four waves, one per SIMD, each a (32 WM) x 128 sub-tile of a (64 WM) x 256 workgroup tile, WM in {4, 5}: 256 / 320 accumulator
 //     registers per lane (AGPRs; the fifth row block of WM = 5 in VGPRs).  320 x 256 turns FFN-up of the BASELINE batch
 //     (12800 x 3072: 600 tiles of 256 x 256 = 2.34 rounds of 256 CUs) into 480 tiles = 1.88 rounds;
-//   * K-tiles of 32 (two k16 steps) in a FOUR-stage ring (4 x 32 / 36 KB) filled by global_load_lds_dwordx4 only, 16 rows x 64 B per
-//     1 KB piece, XOR swizzle (chunk ^= (row >> 2) & 3) on the per-lane SOURCE address -> conflict-free ds_read_b128 of 32-row fragments;
-//     the pieces of K-tile t + 4 are requested ONE PER FOUR MFMAs across the whole of K-tile t (the L1 / TA path takes ~16 cycles per
-//     piece per CU: bunched requests stall the issuing wave for 60-185 cycles each, r05), two K-tiles (~2000 cycles) before they are
-//     read: counted vmcnt(2 NP), never 0 inside the loop;
-//   * ONE barrier per K-tile, between its two steps: by then every wave has read all of tile t (stage free for tile t + 4) and its own
-//     pieces of tile t + 1 have landed;
+//   * K-tiles of 64 in TWO LDS stages (2 x 64 / 72 KB) filled by global_load_lds_dwordx4 only, 8 rows x 128 B per 1 KB piece — whole cache
+//     lines of the operands —, XOR swizzle (chunk ^= (row >> 1) & 7) on the per-lane SOURCE address -> conflict-free ds_read_b128 of
+//     32-row fragments (SQ_LDS_BANK_CONFLICT = 0);
+//   * the 16-18 requests of K-tile t + 1 are spread one per ~3 MFMAs over step 3 of tile t - 1 and steps 0-1 of tile t (a request stalls
+//     the issuing wave ~75 cycles: bunched, they idle the matrix pipe); step 2 is their landing time;
+//   * ONE barrier per K-tile (64-80 MFMAs per wave), between steps 2 and 3: every wave has read all of tile t, tile t + 1 has landed;
 //   * the fragments of step s + 1 are read under the MFMAs of step s (two register sets);
-//   * epilogue: bias / LayerNorm-fold consumer (rstd (acc - mean c) + b', gemm_common.h) / Q scale / GELU on the accumulators, fp16 through
-//     the freed ring so that every global store writes full 128-byte lines.
+//   * ONE loop body with the stage offsets in SGPRs (separately unrolled bodies per stage made hipcc move the accumulators through scratch);
+//   * epilogue: the tile's bias / c columns and its rows' (mean, rstd) wait in LDS since the prologue; two FMAs per output (LayerNorm-fold
+//     consumer rstd (acc - mean c) + b', gemm_common.h; Q scale folded into the coefficients) + GELU, fp16 through the freed ring so that
+//     every global store writes full 128-byte lines.
+// What it reaches and where it is used: in cycles its K loop runs at 84 % of the matrix pipe's issue rate, but the chip lowers its clock to
+// 1.55-1.75 GHz while matrix work and operand traffic coincide (2.2 GHz without the traffic), and with one workgroup per CU nothing runs
+// under a tile's prologue and epilogue (45 % of its cycles).  Per launch 5-13 % ahead of the two-per-CU kernels on the ViT-B/32 batch shapes
+// (0.30 of the MFMA peak on FFN-up), level with k_gemm4.hip on ViT-L/14 shapes; in a two-tower step it LOSES 0.4-2.7 % because the other
+// tower's workgroups can no longer share its CUs.  pick_tile (k_gemm.hip) therefore takes it only when the device is not shared.
 // Numerics: same operands and f32 accumulation as the other kernels; the 32 x 32 x 16 instruction sums k in its own order, so results
-// agree with the 16 x 16 x 32 kernels to f32 rounding of the sums (not bit for bit): tests hold it to the dequantised reference.
+// agree with the 16 x 16 x 32 kernels to f32 rounding of the sums (<= 1 fp16 ulp after the output rounding; tests/test_gpu_gemm32.py).
 //
 // Reference ops replaced: ggml_mul_mat with a weight operand + bias add (+ scale / gelu), clip.cpp:1360-1380 (q/k/v), :1407-1413 (FFN-up),
 // text :1079-1095, :1127-1131.
@@ -139,37 +143,6 @@ __device__ __forceinline__ void g32_step(const G32Ctx<WM, WN> & c, f16v (&acc)[W
     });
 }
 
-#ifdef G32_REGSTAGE
-// experiment: operands through registers (global_load_dwordx4 -> VGPR -> ds_write_b128) instead of LDS-DMA, same LDS image
-template <int WM, int WN, int I>
-__device__ __forceinline__ void g32_rs_load(const G32Ctx<WM, WN> & c, int kt, u32x4 (&stg)[G32<WM, WN>::NP]) {
-    using G = G32<WM, WN>;
-    if constexpr (I < G::NPX) stg[I] = *(const u32x4 *)(c.xg + (size_t)kt * 128 + c.xoff[I]);
-    else stg[I] = *(const u32x4 *)(c.wg + (size_t)kt * 128 + c.woff[I - G::NPX]);
-}
-template <int WM, int WN, int I>
-__device__ __forceinline__ void g32_rs_write(unsigned char * smem, int lane16, int wave, unsigned sbase, const u32x4 (&stg)[G32<WM, WN>::NP]) {
-    using G = G32<WM, WN>;
-    if constexpr (I < G::NPX) *(u32x4 *)(smem + sbase + (wave * G::NPX + I) * 1024 + lane16) = stg[I];
-    else *(u32x4 *)(smem + sbase + G::XB + (wave * G::NPW + (I - G::NPX)) * 1024 + lane16) = stg[I];
-}
-template <int WM, int WN, int W0, int W1, int L0, int L1>
-__device__ __forceinline__ void g32_step_rs(const G32Ctx<WM, WN> & c, f16v (&acc)[WN][WM], const h8 (&wm_)[WN], const h8 (&xm_)[WM], h8 (&wr)[WN], h8 (&xr)[WM],
-                                            const unsigned char * xrd, const unsigned char * wrd, unsigned char * smem, int lane16, int wave, unsigned wbase, int lkt,
-                                            u32x4 (&stg)[G32<WM, WN>::NP]) {
-    constexpr int NM = WM * WN, NR = WM + WN;
-    static_for<0, NM>([&](auto G_) {
-        constexpr int g = decltype(G_)::value;
-        constexpr int a = g / WM, b = g % WM;
-        if constexpr (g < WM) xr[g] = *(const h8 *)(xrd + g * 4096);
-        else if constexpr (g < NR) wr[g - WM] = *(const h8 *)(wrd + (g - WM) * 4096);
-        if constexpr (slot_req(g, NM, W1 - W0) >= 0) g32_rs_write<WM, WN, W0 + slot_req(g, NM, W1 - W0)>(smem, lane16, wave, wbase, stg);
-        if constexpr (slot_req(g, NM, L1 - L0) >= 0) g32_rs_load<WM, WN, L0 + slot_req(g, NM, L1 - L0)>(c, lkt, stg);
-        mfma32<(b < 4)>(acc[a][b], wm_[a], xm_[b]);
-    });
-}
-#endif
-
 template <int WM, int WN, int EPI>
 __global__ void __launch_bounds__(NT32, 1) gemm32_kernel(const GemmParams p) {
     using G = G32<WM, WN>;
@@ -273,13 +246,7 @@ __global__ void __launch_bounds__(NT32, 1) gemm32_kernel(const GemmParams p) {
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                // K-tile 0 and the loads above have landed (hipcc's own counting restarts from zero)
-#ifdef G32_REGSTAGE
-    u32x4 stg[G::NP];
-    static_for<0, G::NP>([&](auto I_) { g32_rs_load<WM, WN, decltype(I_)::value>(c, T > 1 ? 1 : 0, stg); });
-    const int lane16 = lane * 16;
-#else
     if (T > 1) g32_pieces<WM, WN, 0, G::NA>(c, 1, G::STAGE);
-#endif
     raw_barrier32();
 #ifndef G32_ABL_NOREAD
 #pragma unroll
@@ -306,23 +273,12 @@ __global__ void __launch_bounds__(NT32, 1) gemm32_kernel(const GemmParams p) {
     unsigned cur = 0, oth = G::STAGE;
     for (int t = 0; t < T; t++) {
         const bool nx1 = t + 1 < T, nx2 = t + 2 < T;       // (uniform)
-#ifdef G32_REGSTAGE
-        (void)nx1; (void)nx2;
-        const int lkt = t + 2 < T ? t + 2 : T - 1;
-        g32_step_rs<WM, WN, 0, G::NP / 2, 0, 0>(c, acc, w0, x0, w1, x1, smem + (c.xa[1] + (int)cur), smem + (c.wa[1] + (int)cur), smem, lane16, wave, oth, lkt, stg);
-        g32_step_rs<WM, WN, G::NP / 2, G::NP, 0, G::NP / 2>(c, acc, w1, x1, w0, x0, smem + (c.xa[2] + (int)cur), smem + (c.wa[2] + (int)cur), smem, lane16, wave, oth, lkt, stg);
-        g32_step_rs<WM, WN, 0, 0, G::NP / 2, G::NP>(c, acc, w0, x0, w1, x1, smem + (c.xa[3] + (int)cur), smem + (c.wa[3] + (int)cur), smem, lane16, wave, oth, lkt, stg);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        raw_barrier32();
-        g32_step_rs<WM, WN, 0, 0, 0, 0>(c, acc, w1, x1, w0, x0, smem + (c.xa[0] + (int)oth), smem + (c.wa[0] + (int)oth), smem, lane16, wave, oth, lkt, stg);
-#else
         g32_step<WM, WN, G::NA, G::NB>(c, acc, w0, x0, w1, x1, smem + (c.xa[1] + (int)cur), smem + (c.wa[1] + (int)cur), nx1, t + 1, oth);
         g32_step<WM, WN, G::NB, G::NP>(c, acc, w1, x1, w0, x0, smem + (c.xa[2] + (int)cur), smem + (c.wa[2] + (int)cur), nx1, t + 1, oth);
         g32_step<WM, WN, 0, 0>(c, acc, w0, x0, w1, x1, smem + (c.xa[3] + (int)cur), smem + (c.wa[3] + (int)cur), false, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0070);
         raw_barrier32();
         g32_step<WM, WN, 0, G::NA>(c, acc, w1, x1, w0, x0, smem + (c.xa[0] + (int)oth), smem + (c.wa[0] + (int)oth), nx2, t + 2, cur);
-#endif
         const unsigned r0 = cur; cur = oth; oth = r0;
     }
     // (the asm MFMAs are opaque to hipcc's hazard recogniser: let the last ones retire before the accumulators are read)
@@ -369,11 +325,10 @@ __global__ void __launch_bounds__(NT32, 1) gemm32_kernel(const GemmParams p) {
     const int N = p.W.N;
     // output rows through a buffer descriptor: rows past M fall outside it and are dropped by the hardware (no exec masks in the store loop)
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.ldc * 2), 0x00020000);
-#ifndef G32_EPI_STAGED
+#ifdef G32_EPI_DIRECT   // measured alternative (profiles/r06_experiments.txt section 1): fewer cycles, 23 % more HBM write traffic; not the default
     // Straight from the registers: a lane holds 4 consecutive columns (8 j + 4 hi ...) of row l31 per j; v_permlane32_swap pairs j with j + 1
     // so that the lower half-wave holds the 8 columns 16 jp .. + 7 and the upper half-wave 16 jp + 8 .. + 15 of its row: one 16-byte store per
-    // lane, 32 bytes per row per instruction, no LDS round trip and no wait inside the epilogue (the staged form below spends more time in
-    // its two write -> read -> store hand-offs than the fuller lines save).
+    // lane, 32 bytes per row per instruction, no LDS round trip and no wait inside the epilogue.
     (void)stage;
     const unsigned obase = (unsigned)(mb + l31) * (unsigned)(p.ldc * 2) + (unsigned)(n0 + wn * (WN * 32) + 8 * hi) * 2;
 #pragma unroll

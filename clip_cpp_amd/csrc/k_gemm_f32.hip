@@ -76,6 +76,12 @@ void launch_f32(const GemmParams & p, hipStream_t stream) {
 }  // namespace
 
 void launch_gemm_f32(const GemmParams & p, int epilogue, hipStream_t stream) {
+    // the kernel reads Kpad columns of every activation row (the zero weight padding multiplies them): a caller whose rows are shorter would
+    // read past the last row, or multiply NaN garbage into the sums.  Every call site pads its rows; refuse loudly otherwise.
+    if (p.lda < p.W.Kpad) {
+        fprintf(stderr, "clip (hip): launch_gemm_f32: activation rows of %d elements are shorter than the padded depth %d — launch dropped\n", p.lda, p.W.Kpad);
+        return;
+    }
     switch (epilogue) {
     case EPI_F32: launch_f32<EPI_F32>(p, stream); break;
     case EPI_F16: launch_f32<EPI_F16>(p, stream); break;

@@ -15,6 +15,11 @@
 #include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <cerrno>
+#include <atomic>
+#include <thread>
+#include <functional>
 
 #include "model.h"
 
@@ -262,7 +267,7 @@ struct Loader {
 
 // File "<dir>/<basename>.<key>.hbm" = 32-byte header {magic, version, key, image bytes} + the HBM image.
 struct WeightCache {
-    static constexpr uint32_t kVersion = 3;    // bump when the device layout of any tensor changes (2: LayerNorm fold vectors)
+    static constexpr uint32_t kVersion = 4;    // bump when the device layout of any tensor changes (2: LayerNorm fold vectors; 4: f32 tensors of f32 files stay f32)
     bool enabled = false, readable = false;
     std::string path;
     uint64_t key = 0, image_bytes = 0;
@@ -360,12 +365,20 @@ struct WeightCache {
         // one temporary file PER WRITER: clip_amd_model_load_multi loads its G replicas on concurrent threads of one process,
         // and a name built from the pid alone had them all truncate and fill the same inode while the first finisher renamed it into
         // place (a published image with zero-filled holes).  mkstemp gives every thread / process its own file; rename stays atomic.
-        std::string tmp = path + ".tmp.XXXXXX";
-        const int fd = mkstemp(&tmp[0]);
+        // The file is created with open(O_CREAT | O_EXCL, 0666): the KERNEL applies the process umask atomically, so a cache directory shared
+        // between users / services stays shared, and no thread ever touches the umask (the mkstemp + umask(0) / umask(um) read-back
+        // of round 4 could leave the process umask at 0 when two loader threads interleaved).  The suffix is per writer: pid, thread, a counter.
+        static std::atomic<unsigned> seq{0};
+        int fd = -1;
+        std::string tmp;
+        for (int attempt = 0; attempt < 8 && fd < 0; attempt++) {
+            char suf[96];
+            snprintf(suf, sizeof suf, ".tmp.%ld.%zx.%u", (long)getpid(), std::hash<std::thread::id>()(std::this_thread::get_id()), seq.fetch_add(1));
+            tmp = path + suf;
+            fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC, 0666);
+            if (fd < 0 && errno != EEXIST) return;
+        }
         if (fd < 0) return;
-        // mkstemp creates the file 0600; the published image keeps that mode through the rename, and a cache directory shared between
-        // users / services would silently stop being shared (everyone else repacks on every load).  Give it what fopen would have: 0666 & ~umask.
-        { const mode_t um = umask(0); (void)umask(um); (void)fchmod(fd, 0666 & ~um); }
         FILE * f = fdopen(fd, "wb");
         if (!f) { (void)close(fd); (void)remove(tmp.c_str()); return; }
         Header hd;

@@ -1,3 +1,5 @@
+"""Phase stamps of a -DCLIPAMD_G8_TIMING build (k_gemm32.hip / k_gemm4.hip): per launch, the median cycles of a workgroup's prologue / K loop / epilogue and the
+shader clock during the kernel (s_memtime ticks per 100 MHz s_memrealtime tick).  usage: CLIPAMD_G8_STAMPS=FILE python scripts/gemm_bench.py ...; python scripts/g32_stamps.py FILE"""
 import sys, collections
 cur=None; groups=collections.OrderedDict()
 for line in open(sys.argv[1]):
@@ -11,7 +13,5 @@ for k,rows in groups.items():
     t0=min(r[1] for r in rows); 
     tot=[r[4]-r[1] for r in rows]; loop=[r[3]-r[2] for r in rows]; pro=[r[2]-r[1] for r in rows]; epi=[r[4]-r[3] for r in rows]; ack=[r[5]-r[4] for r in rows]
     clk=[(r[5]-r[1])/max(1,(r[7]-r[6]))*100 for r in rows]   # MHz
-    span=(max(r[5] for r in rows)-t0)
     rspan=(max(r[7] for r in rows)-min(r[6] for r in rows))/100.0
-    starts=sorted(r[1]-t0 for r in rows)
-    print(k); print("  wgs %d | cycles: total med %d  prologue %d  loop %d  epilogue %d  ack %d | clock med %.0f MHz | span %d cyc = %.1f us | late starts (>5k cyc): %d, median late start %d" % (len(rows), st.median(tot), st.median(pro), st.median(loop), st.median(epi), st.median(ack), st.median(clk), span, rspan, sum(1 for x in starts if x>5000), st.median([x for x in starts if x>5000] or [0])))
+    print(k); print("  wgs %d | cycles: total med %d  prologue %d  loop %d  epilogue %d  ack %d | clock med %.0f MHz | first start to last end %.1f us" % (len(rows), st.median(tot), st.median(pro), st.median(loop), st.median(epi), st.median(ack), st.median(clk), rspan))
