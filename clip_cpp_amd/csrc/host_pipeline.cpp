@@ -39,8 +39,29 @@ namespace {
 // f32 -> fp16 while packing, round to nearest even: exactly the conversion the im2col kernel would apply to the f32 pixels on the
 // device, so shipping fp16 changes no bit of the result and halves the bytes that cross PCIe (602 -> 301 KB per 224x224 image).
 #ifdef CLIPAMD_HAVE_F16C
+__attribute__((target("avx2,f16c"))) void cvt_f16_avx_plain(const float * src, uint16_t * dst, size_t n) {
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m256 a = _mm256_loadu_ps(src + i), b = _mm256_loadu_ps(src + i + 8);
+        _mm_storeu_si128((__m128i *)(dst + i), _mm256_cvtps_ph(a, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+        _mm_storeu_si128((__m128i *)(dst + i + 8), _mm256_cvtps_ph(b, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+    }
+    for (; i < n; i++) dst[i] = f32_to_f16_bits(src[i]);
+}
+// The destination is the pinned staging buffer: written once, read next by the copy engine, never by a core.  Non-temporal stores skip
+// the read-for-ownership of every destination line (77 MB of the 308 MB a 256-image call otherwise moves through the host's memory
+// controllers: the packers are bandwidth-bound, r06) and keep the source stream in the caches.  The sfence orders them in front of the
+// release that publishes the image to the driving thread.
 __attribute__((target("avx2,f16c"))) void cvt_f16_avx(const float * src, uint16_t * dst, size_t n) {
     size_t i = 0;
+    if (((uintptr_t)dst & 15) == 0) {
+        for (; i + 16 <= n; i += 16) {
+            const __m256 a = _mm256_loadu_ps(src + i), b = _mm256_loadu_ps(src + i + 8);
+            _mm_stream_si128((__m128i *)(dst + i), _mm256_cvtps_ph(a, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+            _mm_stream_si128((__m128i *)(dst + i + 8), _mm256_cvtps_ph(b, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+        }
+        _mm_sfence();
+    }
     for (; i + 16 <= n; i += 16) {
         const __m256 a = _mm256_loadu_ps(src + i), b = _mm256_loadu_ps(src + i + 8);
         _mm_storeu_si128((__m128i *)(dst + i), _mm256_cvtps_ph(a, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
@@ -52,7 +73,12 @@ __attribute__((target("avx2,f16c"))) void cvt_f16_avx(const float * src, uint16_
 void cvt_f16(const float * src, uint16_t * dst, size_t n) {
 #ifdef CLIPAMD_HAVE_F16C
     static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c");
-    if (fast) { cvt_f16_avx(src, dst, n); return; }
+    static const bool nt = !getenv("CLIP_AMD_HOST_NT") || getenv("CLIP_AMD_HOST_NT")[0] != '0';      // (A/B switch)
+    if (fast) {
+        if (nt) cvt_f16_avx(src, dst, n);
+        else cvt_f16_avx_plain(src, dst, n);
+        return;
+    }
 #endif
     for (size_t i = 0; i < n; i++) dst[i] = f32_to_f16_bits(src[i]);     // quant.cpp: the same rounding, scalar
 }
@@ -150,6 +176,25 @@ int host_pipeline_subchunk(int n, bool more_chunks) {
     // against 44.9-45.7 k for one forward of 256 and 39 k for four of 64)
     return more_chunks || n <= 128 ? n : 128;
 }
+// Forward groups of a chunk of n images, in images (every group but the last a multiple of the copy piece).  A single-chunk call of more than
+// 128 images: a SMALL first group, then the rest in one forward (round 6: the first group's forward hides the H2D of the rest — 64 + 192 of
+// 256: 0.35 ms copy, then max(1.05 ms copy of 192, 1.15 ms forward of 64), then 2.45 ms forward of 192 — where two halves of 128 left 1.9 ms of
+// the second forward with nothing beside it; measured profiles/r06_experiments.txt section 6).  CLIP_AMD_HOST_SUBCHUNK=k forces uniform groups of k,
+// CLIP_AMD_HOST_FIRST_GROUP=k another first group (0: uniform halves as in rounds 3-5).
+static std::vector<int> host_pipeline_groups(int n, bool more_chunks, int cp) {
+    static int forced = -1, first = -1;
+    if (forced < 0) { const char * e = getenv("CLIP_AMD_HOST_SUBCHUNK"); forced = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (first < 0) { const char * e = getenv("CLIP_AMD_HOST_FIRST_GROUP"); first = e ? atoi(e) : -2; }
+    std::vector<int> g;
+    if (!forced && !more_chunks && n > 128 && first != 0 && cp > 0) {
+        int g1 = first > 0 ? first : std::max(cp, (n / 4) / cp * cp);
+        g1 = std::min(g1 / cp * cp, n - cp);
+        if (g1 >= cp) { g.push_back(g1); g.push_back(n - g1); return g; }
+    }
+    const int fg = host_pipeline_subchunk(n, more_chunks);
+    for (int i = 0; i < n; i += fg) g.push_back(std::min(fg, n - i));
+    return g;
+}
 static int host_pipeline_copy_piece(int n) {
     static int forced = -1;
     if (forced < 0) { const char * e = getenv("CLIP_AMD_HOST_COPY_PIECE"); forced = e && atoi(e) > 0 ? atoi(e) : 0; }
@@ -195,7 +240,7 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
 
     // Per-chunk geometry (the same for every chunk but the last) and packing progress: packed[c][piece] counts converted images;
     // go[c] opens chunk c's pinned buffer to the packers (chunks 0 and 1 at once, chunk c >= 2 when the H2Ds of chunk c-2 are done).
-    struct ChunkGeo { int b0, bc, fg, cp, ppg, n_grp; };
+    struct ChunkGeo { int b0, bc, cp, n_pieces; std::vector<int> g0, gn; };      // copy pieces of cp images; forward groups [g0, g0 + gn) on piece boundaries
     std::vector<ChunkGeo> geo(n_chunks);
     std::vector<std::vector<std::atomic<int>>> packed(n_chunks);
     std::vector<std::atomic<int>> go(n_chunks);
@@ -203,11 +248,14 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
         ChunkGeo & g = geo[c];
         g.b0 = c * chunk;
         g.bc = std::min(chunk, n - g.b0);
-        g.fg = host_pipeline_subchunk(g.bc, n_chunks > 1);   // images per forward
-        g.cp = host_pipeline_copy_piece(g.fg);               // images per H2D copy (pieces never straddle a forward group)
-        g.ppg = (g.fg + g.cp - 1) / g.cp;                    // pieces per (full) forward group
-        g.n_grp = (g.bc + g.fg - 1) / g.fg;
-        packed[c] = std::vector<std::atomic<int>>((size_t)g.n_grp * g.ppg);
+        g.cp = host_pipeline_copy_piece(g.bc);               // images per H2D copy
+        const std::vector<int> grp = host_pipeline_groups(g.bc, n_chunks > 1, g.cp);   // images per forward
+        for (int at = 0, i = 0; i < (int)grp.size(); at += grp[i], i++) { g.g0.push_back(at); g.gn.push_back(grp[i]); }
+        // (pieces never straddle a forward group: a group that is not a multiple of the piece ends with a short piece, and piece indices
+        //  are counted per group: piece_base[group] + k)
+        g.n_pieces = 0;
+        for (int gnv : g.gn) g.n_pieces += (gnv + g.cp - 1) / g.cp;
+        packed[c] = std::vector<std::atomic<int>>((size_t)g.n_pieces);
         for (auto & a : packed[c]) a.store(0, std::memory_order_relaxed);
         go[c].store(c < 2 ? 1 : 0, std::memory_order_relaxed);
     }
@@ -218,7 +266,9 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
         uint16_t * pin = (uint16_t *)hp.pin_in[c & 1];
         for (int i = t; i < g.bc; i += step) {                  // image i of the chunk; pieces fill in order
             cvt_f16(imgs[g.b0 + i].data, pin + per * i, per);
-            packed[c][(size_t)(i / g.fg) * g.ppg + (i % g.fg) / g.cp].fetch_add(1, std::memory_order_release);
+            int gi = 0, pb = 0;                                 // the image's forward group and that group's first piece index
+            while (gi + 1 < (int)g.g0.size() && i >= g.g0[gi + 1]) { pb += (g.gn[gi] + g.cp - 1) / g.cp; gi++; }
+            packed[c][(size_t)pb + (i - g.g0[gi]) / g.cp].fetch_add(1, std::memory_order_release);
         }
     };
     const bool self_pack = P == 1;      // no helper threads: the driving thread packs chunk c itself, right before it enqueues it
@@ -242,8 +292,8 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
             // (the one-thread path used to pack EVERY chunk before driving any — with only two pinned buffers chunk c >= 2
             // overwrote chunk c - 2 before its copies had been issued; now chunk c is packed here, behind the wait for its buffer)
             if (self_pack && ok) pack_chunk(c, 0, 1);
-            for (int gi = 0; gi < g.n_grp && ok; gi++) {
-                const int g0 = gi * g.fg, gn = std::min(g.fg, g.bc - g0);
+            for (int gi = 0, pb = 0; gi < (int)g.g0.size() && ok; pb += (g.gn[gi] + g.cp - 1) / g.cp, gi++) {
+                const int g0 = g.g0[gi], gn = g.gn[gi];
                 // The patch stage (im2col + patch GEMM + class rows) of a forward group runs PER COPY PIECE, behind that piece's H2D, while
                 // the later pieces are still crossing PCIe; the layers run once on the whole group when its last piece is in (VERDICT r2
                 // item 7: before, the whole forward waited for the last piece).  Groups the workspace cannot hold in one chunk, and the
@@ -254,7 +304,7 @@ bool encode_images_from_host(clip_ctx * ctx, const clip_image_f32 * imgs, int n,
                 for (int k = 0; k * g.cp < gn && ok; k++) {
                     const int s0 = g0 + k * g.cp, sn = std::min(g.cp, g0 + gn - s0);
                     const auto tw0 = std::chrono::steady_clock::now();
-                    while (packed[c][(size_t)gi * g.ppg + k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
+                    while (packed[c][(size_t)pb + k].load(std::memory_order_acquire) < sn) std::this_thread::yield();
                     t_wait_pack += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
                     ok = ok && hipMemcpyAsync(dev + per * s0, pin + per * s0, per_bytes * sn, hipMemcpyHostToDevice, hp.copy_stream) == hipSuccess;
                     if (staged && ok) {

@@ -86,6 +86,8 @@ def lib():
         L.orc_h2f.restype = C.c_float
         L.orc_h2f.argtypes = [C.c_uint16]
         L.orc_mul_mat.argtypes = [i32, vp, i64, i64, f32p, i64, f32p, i32, i32]
+        L.orc_set_dot_simd.restype = i32
+        L.orc_set_dot_simd.argtypes = [i32]
         L.orc_layer_norm.argtypes = [f32p, f32p, i64, i64, f32p, f32p, C.c_float]
         L.orc_activation.argtypes = [f32p, i64, i32, i32]
         L.orc_softmax_rows.argtypes = [f32p, i64, i64, i32]
@@ -116,6 +118,20 @@ def dequantize(type_id, raw, nrows, k):
     out = np.empty((nrows, k), dtype=np.float32)
     lib().orc_dequantize(type_id, raw.ctypes.data_as(C.c_void_p), _fp(out), nrows, k)
     return out
+
+
+DOT_SCALAR, DOT_AVX2, DOT_VNNI, DOT_BEST = 0, 1, 2, -1
+
+
+def set_dot_simd(form=DOT_BEST):
+    """Form of the integer dot products of the block-quantised mul_mat (clip_oracle.cpp mul_mat_quant_simd): 0 scalar loop, 1 AVX2 vpmaddubsw,
+    2 AVX-512 VNNI vpdpbusd, -1 the best the CPU has (default).  Every form gives the same bits (tests/test_oracle_golden.py).  Returns the form in use."""
+    return lib().orc_set_dot_simd(form)
+
+
+def dot_simd_name(form=None):
+    form = set_dot_simd(DOT_BEST) if form is None else form
+    return {0: "scalar", 1: "AVX2 vpmaddubsw", 2: "AVX-512 VNNI vpdpbusd"}[form]
 
 
 def mul_mat(type_id, raw, N, K, X, mode=MODE_FAITHFUL, n_threads=0):

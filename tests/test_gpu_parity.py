@@ -243,12 +243,29 @@ def test_full_size_properties_b32_q4_0_batch256(gpu, fixture_cache):
         assert np.array_equal(one, clip.encode_images(imgs[i:i + 1])), i     # (deterministic: ordered fix-up)
         assert one_minus_cos(one, full[i:i + 1])[0] <= 1e-6, i
         np.testing.assert_allclose(one[0], full[i], atol=3e-4)               # fp16 activation roundings flip on re-association
-    perm = np.random.default_rng(0).permutation(256)
-    assert np.array_equal(clip.encode_images(imgs[perm]), full[perm])
-    sub = clip.encode_images(imgs[:128])                                      # same (unsplit) schedule -> same bits
-    assert np.array_equal(sub, full[:128])
+    # permutation equivariance.  The host pipeline runs a 256-image call as two forwards — 64 + 192 images since round 6 (the first forward hides
+    # the H2D of the rest; host_pipeline.cpp host_pipeline_groups) — and the two row counts use different GEMM schedules: bit for bit for a
+    # permutation that keeps every image in its forward group, fp32 re-association (1 - cos <= 1e-6) for one that does not.
+    rng = np.random.default_rng(0)
+    perm_in = np.concatenate([rng.permutation(64), 64 + rng.permutation(192)])
+    assert np.array_equal(clip.encode_images(imgs[perm_in]), full[perm_in])
+    perm = rng.permutation(256)
+    got = clip.encode_images(imgs[perm])
+    assert np.all(one_minus_cos(got, full[perm]) <= 1e-6)
+    np.testing.assert_allclose(got, full[perm], atol=3e-4)
+    sub = clip.encode_images(imgs[:128])                                      # one forward of 128: another schedule than 64 + 192
+    assert np.all(one_minus_cos(sub, full[:128]) <= 1e-6)
     sub32 = clip.encode_images(imgs[:32])
     assert np.all(one_minus_cos(sub32, full[:32]) <= 1e-6)
+    # the device-pointer entry point runs ONE forward of 256: same embeddings to re-association, and bit-identical under any permutation
+    torch = pytest.importorskip("torch")
+    d_in, d_out = torch.from_numpy(imgs).cuda(), torch.empty((256, 512), dtype=torch.float32, device="cuda")
+    clip.encode_images_device(d_in.data_ptr(), 256, d_out.data_ptr(), True); clip.synchronize()
+    dev = d_out.cpu().numpy()
+    assert np.all(one_minus_cos(dev, full) <= 1e-6)
+    d_in2 = torch.from_numpy(imgs[perm]).cuda()
+    clip.encode_images_device(d_in2.data_ptr(), 256, d_out.data_ptr(), True); clip.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), dev[perm])
 
 
 @pytest.mark.parametrize("config,ftype,n_img", [("b32", "q4_0", 40), ("b32", "f16", 6), ("tiny14", "q5_1", 9)])

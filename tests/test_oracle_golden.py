@@ -253,3 +253,50 @@ def test_integer_dot_path_equals_its_stated_arithmetic_bit_for_bit(tname, oracle
     # q8_1: s == d * sum(q) exactly as stated
     if is1:
         assert np.array_equal(sx, (q.sum(-1).astype(np.float32) * d).astype(np.float32))
+
+
+@pytest.mark.parametrize("tname", ["q4_0", "q5_0", "q8_0", "q4_1", "q5_1"])
+def test_simd_integer_dot_forms_are_bit_identical_to_the_scalar_loop(tname, oracle_lib):
+    """Round 6: the oracle's block-quantised mul_mat has a SIMD form of the integer dot products — vpmaddubsw + vpmaddwd
+    (AVX2, the shape of ggml's x86 vec_dot_q*_q8_*) and vpdpbusd (AVX-512 VNNI) — cache-blocked over 32 activation rows; bench.py's cpu_baseline
+    times it.  The integer sum of a block is exact in every form and the f32 accumulation over the blocks keeps the scalar path's order, so the
+    outputs must be the SAME BITS: odd shapes, several threads, saturating activations (|q| = 127) and a raw q8_0 weight byte of -128."""
+    tid = ref.GGML_TYPES[tname]
+    best = ref.set_dot_simd(ref.DOT_BEST)
+    assert best >= 1, "the oracle is built for x86-64-v3: AVX2 must be there"
+    rng = np.random.default_rng(11)
+    try:
+        for (N, K, M, threads) in [(24, 256, 9, 1), (130, 768, 77, 4), (64, 64, 33, 2), (17, 3072, 5, 3)]:
+            W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+            W[:, rng.integers(0, K, 3)] *= 9.0
+            X = (rng.standard_normal((M, K)) * 1.7).astype(np.float32)
+            X[0, :32] = 3.0                                     # a block whose every quant is +127
+            X[-1, 32:64] = -2.5                                 # ... and -127
+            raw = ref.quantize(tid, W).copy()
+            if tname == "q8_0":
+                raw.reshape(N, K // 32, 34)[1, 0, 2 + 5] = 0x80     # int8 -128 in a weight block (never produced by the quantiser; a file may hold it)
+            ref.set_dot_simd(ref.DOT_SCALAR)
+            base = ref.mul_mat(tid, raw, N, K, X, ref.MODE_FAITHFUL, n_threads=threads)
+            assert np.all(np.isfinite(base))
+            for form in range(1, best + 1):
+                assert ref.set_dot_simd(form) == form
+                y = ref.mul_mat(tid, raw, N, K, X, ref.MODE_FAITHFUL, n_threads=threads)
+                assert np.array_equal(y, base), (tname, N, K, M, form, float(np.abs(y - base).max()))
+    finally:
+        ref.set_dot_simd(ref.DOT_BEST)
+
+
+def test_simd_oracle_embeddings_equal_the_scalar_oracle(oracle_lib, fixture_cache):
+    """... and end to end: both towers of a quantised two-tower model, scalar vs best form: identical embeddings."""
+    p = fixtures.cached_model(fixture_cache, "tiny", "q4_0")
+    orc = ref.OracleModel(p)
+    imgs = fixtures.synthetic_images(3, fixtures.CONFIGS["tiny"]["v"]["S"], seed=5)
+    ids = [49406, 320, 1125, 539, 49407]
+    try:
+        ref.set_dot_simd(ref.DOT_SCALAR)
+        a_i, a_t = orc.image_batch_encode(imgs, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=2), orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=2)
+        ref.set_dot_simd(ref.DOT_BEST)
+        b_i, b_t = orc.image_batch_encode(imgs, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=2), orc.text_encode(ids, normalize=True, mode=ref.MODE_FAITHFUL, n_threads=2)
+    finally:
+        ref.set_dot_simd(ref.DOT_BEST)
+    assert np.array_equal(a_i, b_i) and np.array_equal(a_t, b_t)
