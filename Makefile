@@ -11,7 +11,7 @@ SRC     := clip_cpp_amd/csrc
 OUT     := clip_cpp_amd/build
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result -Wno-inline-asm -Wno-bitwise-instead-of-logical -Iinclude --offload-arch=$(ARCH) -DCLIPAMD_TEST_HOOKS=$(hooks)
 HOST    := gguf quant load forward tokenizer preprocess image_io image_formats jpeg_decode host_pipeline api
-KERNELS := k_attn k_misc k_preproc k_gemm k_gemm8 k_gemm4 k_gemm32 k_gemm_f32 k_skinny k_gemm_ring k_fold
+KERNELS := k_attn k_attn_f32 k_misc k_preproc k_gemm k_gemm8 k_gemm4 k_gemm32 k_gemm_f32 k_skinny k_gemm_ring k_fold
 WTS     := 0 1 2 3 4 5
 OBJS    := $(HOST:%=$(OUT)/%.cpp.o) $(KERNELS:%=$(OUT)/%.hip.o) $(WTS:%=$(OUT)/k_gemm_wt%.o) $(WTS:%=$(OUT)/k_skinny_wt%.o) $(WTS:%=$(OUT)/k_gemm_ring_wt%.o)
 

@@ -23,7 +23,7 @@ ARCH = "gfx950"
 
 HOST_SOURCES = ["gguf.cpp", "quant.cpp", "load.cpp", "forward.cpp", "tokenizer.cpp", "preprocess.cpp", "image_io.cpp", "image_formats.cpp",
                 "jpeg_decode.cpp", "host_pipeline.cpp", "api.cpp"]
-HIP_SOURCES = ["k_attn.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip", "k_gemm4.hip", "k_gemm32.hip", "k_gemm_f32.hip", "k_skinny.hip", "k_gemm_ring.hip", "k_fold.hip"]
+HIP_SOURCES = ["k_attn.hip", "k_attn_f32.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip", "k_gemm4.hip", "k_gemm32.hip", "k_gemm_f32.hip", "k_skinny.hip", "k_gemm_ring.hip", "k_fold.hip"]
 GEMM_WTYPES = [0, 1, 2, 3, 4, 5]
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-inline-asm", "-Wno-bitwise-instead-of-logical",

@@ -115,6 +115,19 @@ double weight_bytes(const DevWeight & W) {
     return 0;
 }
 
+// f32 GGUF file: the activations between the kernels are f32 too (k_gemm_f32.hip act_f32, k_attn_f32.hip; the half_t workspace pointers then
+// address float rows: twice the elements are carved).  CLIP_AMD_F32_ACTS=0 at load time restores the fp16 activations of round 5 (A/B: clip_ctx::f32_acts).
+bool acts_f32(const clip_ctx * ctx, const DevTower & tw) {
+    return ctx->f32_acts && !tw.layers.empty() && tw.layers[0].qkv.wtype == W_F32 && tw.layers[0].o.wtype == W_F32 && tw.layers[0].ff1.wtype == W_F32 && tw.layers[0].ff2.wtype == W_F32 &&
+           tw.proj.wtype == W_F32;
+}
+// LayerNorm of rows of x into an activation buffer: fp16, or f32 behind the same pointer
+void layernorm_act(bool f32, const float * x, int ldx, const int * in_rows, int in_row_mul, const float * w, const float * b, float eps, int rows, int h, half_t * dst,
+                   hipStream_t s) {
+    if (f32) launch_layernorm(x, ldx, in_rows, in_row_mul, w, b, eps, rows, h, nullptr, 0, (float *)dst, h, s);
+    else launch_layernorm(x, ldx, in_rows, in_row_mul, w, b, eps, rows, h, dst, h, nullptr, 0, s);
+}
+
 // the device carries other work next to this context's: declared by the caller, or this context is / has a busy sibling (two-tower pair calls)
 bool device_shared(const clip_ctx * ctx) { return ctx->device_shared || ctx->sibling_busy || ctx->owner != nullptr; }
 
@@ -342,38 +355,41 @@ bool run_layers(clip_ctx * ctx, const DevTower & tw, int rows, int h, int nh, in
     const int dh = h / nh;
     const float qscale = 1.0f / sqrtf((float)dh);
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    const bool f32 = acts_f32(ctx, tw);                       // f32 file: xn / qkv / att / mid hold float rows
     for (size_t li = 0; li < tw.layers.size(); li++) {
         const DevLayer & l = tw.layers[li];
         const LayerPanels lp = dequant_layer(ctx, l, rows, resp ? resp + 4 * li : nullptr);
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
-            launch_layernorm(x, h, nullptr, 1, l.ln1_w, l.ln1_b, eps, rows, h, xn, h, nullptr, 0, s);
+            layernorm_act(f32, x, h, nullptr, 1, l.ln1_w, l.ln1_b, eps, rows, h, xn, s);
         }
         GemmParams p;
         p.A = xn; p.lda = h; p.M = rows; p.W = l.qkv; p.bias = l.qkv_b; p.out = qkv; p.ldc = 3 * h; p.w16_pre = lp.qkv;
         p.qscale = qscale; p.qcols = h;   // Q = (W_q x + b_q) / sqrt(d_head): scale after bias (clip.cpp:1363)
+        p.act_f32 = f32;
         gemm(ctx, "gemm_qkv", p, EPI_F16);
         {
             const double afl = 4.0 * (double)nseq * nh * (double)max_len * max_len * dh;
             ProfScope ps(ctx, "attention", nseq * nh, max_len, dh, afl, (double)rows * h * 8);
-            if (!launch_attention(qkv, att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s)) {
+            if (!(f32 ? launch_attention_f32((const float *)qkv, (float *)att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s)
+                      : launch_attention(qkv, att, nseq, T_uniform, d_seq_start, max_len, h, nh, causal, s))) {
                 fprintf(stderr, "clip (hip): attention kernel does not support T=%d d_head=%d\n", max_len, dh);
                 return false;
             }
         }
         if (prune_last && li + 1 == tw.layers.size()) break;     // the rest of the last layer runs on the pooled rows only (pooled_tail)
         GemmParams po;
-        po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x; po.w16_pre = lp.o;
+        po.A = att; po.lda = h; po.M = rows; po.W = l.o; po.bias = l.o_b; po.out = x; po.ldc = h; po.resid = x; po.w16_pre = lp.o; po.act_f32 = f32;
         gemm(ctx, "gemm_out", po, EPI_RESID_F32);
         {
             ProfScope ps(ctx, "layernorm", rows, h, 0, 0, (double)rows * h * 6);
-            launch_layernorm(x, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, rows, h, xn, h, nullptr, 0, s);
+            layernorm_act(f32, x, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, rows, h, xn, s);
         }
         GemmParams p1;
-        p1.A = xn; p1.lda = h; p1.M = rows; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = mid; p1.ldc = ff; p1.w16_pre = lp.ff1;
+        p1.A = xn; p1.lda = h; p1.M = rows; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = mid; p1.ldc = ff; p1.w16_pre = lp.ff1; p1.act_f32 = f32;
         gemm(ctx, "gemm_ffn_up", p1, act);
         GemmParams p2;
-        p2.A = mid; p2.lda = ff; p2.M = rows; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = x; p2.ldc = h; p2.resid = x; p2.w16_pre = lp.ff2;
+        p2.A = mid; p2.lda = ff; p2.M = rows; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = x; p2.ldc = h; p2.resid = x; p2.w16_pre = lp.ff2; p2.act_f32 = f32;
         gemm(ctx, "gemm_ffn_down", p2, EPI_RESID_F32);
     }
     return true;
@@ -447,22 +463,26 @@ bool pooled_tail(clip_ctx * ctx, const DevLayer & l, int n, int h, int ff, float
                  int in_row_mul, float * xp, half_t * ap, half_t * xnp, half_t * midp) {
     hipStream_t s = ctx->stream;
     const int act = ctx->use_gelu ? EPI_GELU_F16 : EPI_QGELU_F16;
+    const bool f32 = ctx->f32_acts && l.o.wtype == W_F32 && l.ff1.wtype == W_F32 && l.ff2.wtype == W_F32;     // f32 file: att / ap / xnp / midp hold float rows
     {
         ProfScope ps(ctx, "gather_pooled", n, h, 0, 0, (double)n * h * 12);
-        launch_gather_rows(x, att, in_rows, in_row_mul, n, h, xp, ap, s);
+        if (f32) {
+            launch_gather_rows(x, nullptr, in_rows, in_row_mul, n, h, xp, nullptr, s);
+            launch_gather_rows((const float *)att, nullptr, in_rows, in_row_mul, n, h, (float *)ap, nullptr, s);
+        } else launch_gather_rows(x, att, in_rows, in_row_mul, n, h, xp, ap, s);
     }
     GemmParams po;
-    po.A = ap; po.lda = h; po.M = n; po.W = l.o; po.bias = l.o_b; po.out = xp; po.ldc = h; po.resid = xp;
+    po.A = ap; po.lda = h; po.M = n; po.W = l.o; po.bias = l.o_b; po.out = xp; po.ldc = h; po.resid = xp; po.act_f32 = f32;
     gemm(ctx, "gemm_out_pooled", po, EPI_RESID_F32);
     {
         ProfScope ps(ctx, "layernorm", n, h, 0, 0, (double)n * h * 6);
-        launch_layernorm(xp, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, n, h, xnp, h, nullptr, 0, s);
+        layernorm_act(f32, xp, h, nullptr, 1, l.ln2_w, l.ln2_b, eps, n, h, xnp, s);
     }
     GemmParams p1;
-    p1.A = xnp; p1.lda = h; p1.M = n; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = midp; p1.ldc = ff;
+    p1.A = xnp; p1.lda = h; p1.M = n; p1.W = l.ff1; p1.bias = l.ff1_b; p1.out = midp; p1.ldc = ff; p1.act_f32 = f32;
     gemm(ctx, "gemm_ffn_up_pooled", p1, act);
     GemmParams p2;
-    p2.A = midp; p2.lda = ff; p2.M = n; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = xp; p2.ldc = h; p2.resid = xp;
+    p2.A = midp; p2.lda = ff; p2.M = n; p2.W = l.ff2; p2.bias = l.ff2_b; p2.out = xp; p2.ldc = h; p2.resid = xp; p2.act_f32 = f32;
     gemm(ctx, "gemm_ffn_down_pooled", p2, EPI_RESID_F32);
     return true;
 }
@@ -812,17 +832,18 @@ bool vision_stage_begin(clip_ctx * ctx, int Bc, VisionStage & st) {
         st.stats = c.take<float2>((size_t)(h / 16) * st.st_stride);
         st.mu = c.take<float>((size_t)2 * st.st_stride);      // centring offsets of the folded LayerNorms (two buffers, ping-pong)
         st.x = c.take<float>((size_t)rows * h);
-        st.xn = c.take<half_t>((size_t)rows * h);
-        st.qkv = c.take<half_t>((size_t)rows * 3 * h);
-        st.att = c.take<half_t>((size_t)rows * h);
-        st.mid = c.take<half_t>((size_t)rows * ff);
+        const size_t aw = acts_f32(ctx, V) ? 2 : 1;                // f32 file: the activation buffers hold float rows
+        st.xn = c.take<half_t>(aw * rows * h);
+        st.qkv = c.take<half_t>(aw * rows * 3 * h);
+        st.att = c.take<half_t>(aw * rows * h);
+        st.mid = c.take<half_t>(aw * rows * ff);
         st.col = c.take<half_t>((size_t)Bc * Np * V.patch.Kpad);
-        st.pooled = c.take<half_t>((size_t)Bc * h);
+        st.pooled = c.take<half_t>(aw * Bc * h);
         st.emb = c.take<float>((size_t)Bc * proj);
         st.xp = c.take<float>((size_t)Bc * h);                // pooled rows of the last layer (pooled_tail)
-        st.ap = c.take<half_t>((size_t)Bc * h);
-        st.xnp = c.take<half_t>((size_t)Bc * h);
-        st.midp = c.take<half_t>((size_t)Bc * ff);
+        st.ap = c.take<half_t>(aw * Bc * h);
+        st.xnp = c.take<half_t>(aw * Bc * h);
+        st.midp = c.take<half_t>(aw * Bc * ff);
     };
     Carver sizer(nullptr);
     carve(sizer);
@@ -885,14 +906,15 @@ bool vision_stage_finish(clip_ctx * ctx, const VisionStage & st, float * d_out, 
         if (!run_layers_fold(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, st.stats, st.st_stride, ctx->ln_fold_centre ? st.mu : nullptr, prune, resident_panels(ctx, V, 0, rows))) return false;
     } else if (!run_layers(ctx, V, rows, h, nh, ff, hp.eps, Bc, T, nullptr, T, false, x, st.xn, st.qkv, st.att, st.mid, prune, resident_panels(ctx, V, 0, rows))) return false;
     // CLS pool + post-LN (:1426-1438): LayerNorm with a strided row gather (row b*T)
+    const bool f32 = acts_f32(ctx, V);
     if (prune) {
         if (!pooled_tail(ctx, V.layers.back(), Bc, h, ff, hp.eps, x, st.att, nullptr, T, st.xp, st.ap, st.xnp, st.midp)) return false;
-        launch_layernorm(st.xp, h, nullptr, 1, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
+        layernorm_act(f32, st.xp, h, nullptr, 1, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, s);
     } else {
-        launch_layernorm(x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, h, nullptr, 0, s);
+        layernorm_act(f32, x, h, nullptr, T, V.post_ln_w, V.post_ln_b, hp.eps, Bc, h, st.pooled, s);
     }
     GemmParams pj;
-    pj.A = st.pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = st.emb; pj.ldc = proj;
+    pj.A = st.pooled; pj.lda = h; pj.M = Bc; pj.W = V.proj; pj.out = st.emb; pj.ldc = proj; pj.act_f32 = f32;
     gemm(ctx, "gemm_proj", pj, EPI_F32);   // projection, no bias (:1443)
     launch_l2norm(st.emb, d_out, Bc, proj, normalize, s);  // (:1446-1455)
     return launch_ok("clip_image_batch_encode") && guard_check(ctx, "clip_image_batch_encode");
@@ -903,7 +925,8 @@ int vision_max_chunk(const clip_ctx * ctx) {
     const int S = hp.image_size, P = hp.patch_size, G = S / P, Np = G * G, T = Np + 1;
     const int h = hp.hidden_size, ff = hp.n_intermediate;
     // images are processed in chunks so that the workspace stays bounded (<= ~6 GB even for ViT-H)
-    const size_t per_img = (size_t)T * ((size_t)h * 4 + (size_t)h * 2 * 2 + (size_t)3 * h * 2 + (size_t)ff * 2) + (size_t)Np * ctx->vision.patch.Kpad * 2;
+    const size_t aw = acts_f32(ctx, ctx->vision) ? 2 : 1;
+    const size_t per_img = (size_t)T * ((size_t)h * 4 + aw * ((size_t)h * 2 * 2 + (size_t)3 * h * 2 + (size_t)ff * 2)) + (size_t)Np * ctx->vision.patch.Kpad * 2;
     return (int)std::min<size_t>(1024, std::max<size_t>(1, ((size_t)6 << 30) / per_img));
 }
 
@@ -961,18 +984,19 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         stats = c.take<float2>((size_t)(h / 16) * st_stride);
         mu = c.take<float>((size_t)2 * st_stride);
         x = c.take<float>((size_t)rows * h);
-        xn = c.take<half_t>((size_t)rows * h);
-        qkv = c.take<half_t>((size_t)rows * 3 * h);
-        att = c.take<half_t>((size_t)rows * h);
-        mid = c.take<half_t>((size_t)rows * ff);
-        pooled = c.take<half_t>((size_t)n_texts * h);
+        const size_t aw = acts_f32(ctx, Tw) ? 2 : 1;               // f32 file: the activation buffers hold float rows
+        xn = c.take<half_t>(aw * rows * h);
+        qkv = c.take<half_t>(aw * rows * 3 * h);
+        att = c.take<half_t>(aw * rows * h);
+        mid = c.take<half_t>(aw * rows * ff);
+        pooled = c.take<half_t>(aw * n_texts * h);
         emb = c.take<float>((size_t)n_texts * proj);
         seq = c.take<int>((size_t)n_texts + 1);
         last = c.take<int>((size_t)n_texts);
         xp = c.take<float>((size_t)n_texts * h);
-        ap = c.take<half_t>((size_t)n_texts * h);
-        xnp = c.take<half_t>((size_t)n_texts * h);
-        midp = c.take<half_t>((size_t)n_texts * ff);
+        ap = c.take<half_t>(aw * n_texts * h);
+        xnp = c.take<half_t>(aw * n_texts * h);
+        midp = c.take<half_t>(aw * n_texts * ff);
     };
     float *x, *emb;
     half_t *xn, *qkv, *att, *mid, *pooled;
@@ -1070,12 +1094,12 @@ bool text_forward_device(clip_ctx * ctx, const int32_t * d_ids, const int32_t * 
         // final LN on the pooled (last) row only — LayerNorm is row-wise, so LN-then-gather == gather-then-LN (:1146-1155)
         if (prune) {    // ... and so is everything behind the last layer's attention: out-projection + FFN on the n_texts last-token rows only
             if (!pooled_tail(ctx, Tw.layers.back(), n_texts, h, ff, hp.eps, x, att, last, 1, xp, ap, xnp, midp)) return false;
-            launch_layernorm(xp, h, nullptr, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+            layernorm_act(acts_f32(ctx, Tw), xp, h, nullptr, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, s);
         } else {
-            launch_layernorm(x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, h, nullptr, 0, s);
+            layernorm_act(acts_f32(ctx, Tw), x, h, last, 1, Tw.post_ln_w, Tw.post_ln_b, hp.eps, n_texts, h, pooled, s);
         }
         GemmParams pj;
-        pj.A = pooled; pj.lda = h; pj.M = n_texts; pj.W = Tw.proj; pj.out = emb; pj.ldc = proj;
+        pj.A = pooled; pj.lda = h; pj.M = n_texts; pj.W = Tw.proj; pj.out = emb; pj.ldc = proj; pj.act_f32 = acts_f32(ctx, Tw);
         gemm(ctx, "gemm_proj", pj, EPI_F32);     // (:1160)
         launch_l2norm(emb, d_out, n_texts, proj, normalize, s);  // (:1163-1166)
         return true;

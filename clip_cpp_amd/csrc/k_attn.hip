@@ -333,6 +333,15 @@ void launch_inst(const AttnParams & p, int nseq, hipStream_t stream) {
     const int units = (NT + QB - 1) / QB;
     int qs = 1;
     if (nseq * p.n_head <= 64 && units > 4) qs = (units + 3) / 4 < 4 ? (units + 3) / 4 : 4;
+#ifdef CLIPAMD_ATTN_ABL   // tuning builds: CLIP_AMD_ATTN_LDS_PAD=bytes of extra dynamic LDS per workgroup (e.g. 20000 at T = 257: ONE workgroup per CU instead of two)
+    static const size_t pad = [] { const char * e = getenv("CLIP_AMD_ATTN_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    if (pad && smem + pad <= 160 * 1024) {
+        static unsigned long long lds_ok2 = 0;
+        opt_in_dynamic_lds(attn_kernel<NT, DKS, DT, DHR>, smem + pad, lds_ok2);
+        hipLaunchKernelGGL((attn_kernel<NT, DKS, DT, DHR>), dim3(nseq * p.n_head, qs), dim3(256), smem + pad, stream, p);
+        return;
+    }
+#endif
     hipLaunchKernelGGL((attn_kernel<NT, DKS, DT, DHR>), dim3(nseq * p.n_head, qs), dim3(256), smem, stream, p);
 }
 

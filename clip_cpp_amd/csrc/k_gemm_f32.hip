@@ -6,8 +6,9 @@
 // 1443; text :1079-1160).  Until round 4 the loader rounded f32 linear weights to fp16 (load.cpp) — narrower than the reference for that
 // file type (VERDICT r4 missing #4).  Now an f32 file keeps its weights in f32 in HBM (W_F32) and every weight GEMM of such a model runs
 // here: products and sums in f32 (the MFMA is an fmaf chain, bit for bit: MI355X_MICROARCH.md), 1/16 of the fp16 matrix rate — an f32 file
-// is a debugging / reference format, not a benchmarked configuration.  The ACTIVATIONS stay what the rest of the pipeline produces: fp16
-// (LayerNorm output, attention output, GELU output), widened exactly — the one place this path is still narrower than ggml's f32 x f32.
+// is a debugging / reference format, not a benchmarked configuration.  Since round 6 the ACTIVATIONS of such a model are f32 too
+// (GemmParams::act_f32: LayerNorm output, q/k/v, attention output, GELU output — forward.cpp): f32 x f32 as in ggml, nothing narrower than the
+// reference anywhere for this file type; the fp16-activation form (AF32 = false) remains for callers that hand in fp16 rows (kernel test hooks).
 //
 // Mapping: workgroup = 64 weight rows x 64 activation rows, 4 waves; wave w owns weight rows 16 w ... 16 w + 15 against all 64 activation
 // rows = 1 x 4 accumulator fragments in the layout of the other GEMM kernels (weight = MFMA "A" operand: a lane ends up with 4 consecutive
@@ -15,6 +16,8 @@
 // (4 consecutive k) and 8 bytes of each of its 4 activation rows per step of 16 k; MFMA step s of the four multiplies k = 4 (lane >> 4) + s
 // on BOTH operands, i.e. the 16 k of a step are consumed in a permuted but fixed order (deterministic; f32 accumulation).
 // The LayerNorm fold, the small-M kernels and the fp16 panels are not used with f32 weights (forward.cpp / load.cpp).
+
+#include <type_traits>
 
 #include "gemm_common.h"
 
@@ -24,7 +27,31 @@ namespace {
 
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 
+// the fp16-output epilogues with f32 stores (act_f32): bias, Q scale after the bias (clip.cpp:1363), GELU — on the accumulator layout of gemm_common.h
 template <int EPI>
+__device__ __forceinline__ void epilogue_f32_out(const GemmParams & p, f4 (&acc)[1][4], int n0, int m0, int frow, int fgrp) {
+    const int n = n0 + fgrp * 4;
+    if (n >= p.W.N) return;
+    const f4 bias = p.bias ? *(const f4 *)(p.bias + n) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int m = m0 + b * 16 + frow;
+        if (m >= p.M) continue;
+        f4 v = acc[0][b] + bias;
+        if constexpr (EPI == EPI_F16) {
+            if (n < p.qcols) v = v * p.qscale;
+        } else if constexpr (EPI == EPI_GELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
+        } else if constexpr (EPI == EPI_QGELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = gelu_quick(v[r]);
+        }
+        *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
+    }
+}
+
+template <int EPI, bool AF32>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -35,27 +62,29 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmParams p) {
     int wr = n0 + frow;
     wr = wr < p.W.Npad ? wr : p.W.Npad - 1;                                                // (rows N .. Npad - 1 are zero)
     const float * wrow = (const float *)p.W.w16 + (size_t)wr * p.W.Kpad + 4 * fgrp;
-    const half_t * xrow[4];
+    typedef typename std::conditional<AF32, float, half_t>::type xel_t;
+    typedef typename std::conditional<AF32, f4, h4_t>::type xv_t;
+    const xel_t * xrow[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         int m = m0 + b * 16 + frow;
         m = m < p.M ? m : p.M - 1;
-        xrow[b] = p.A + (size_t)m * p.lda + 4 * fgrp;
+        xrow[b] = (const xel_t *)p.A + (size_t)m * p.lda + 4 * fgrp;
     }
     f4 acc[1][4];
 #pragma unroll
     for (int b = 0; b < 4; b++) acc[0][b] = (f4){0.f, 0.f, 0.f, 0.f};
     const int nk = p.W.Kpad / 16;
     f4 wv = *(const f4 *)wrow;
-    h4_t xv[4];
+    xv_t xv[4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) xv[b] = *(const h4_t *)xrow[b];
+    for (int b = 0; b < 4; b++) xv[b] = *(const xv_t *)xrow[b];
     for (int kt = 0; kt < nk; kt++) {
         const int kn = (kt + 1 < nk ? kt + 1 : kt) * 16;                                   // next step's operands in flight under this step's MFMAs
         const f4 wn = *(const f4 *)(wrow + kn);
-        h4_t xn[4];
+        xv_t xn[4];
 #pragma unroll
-        for (int b = 0; b < 4; b++) xn[b] = *(const h4_t *)(xrow[b] + kn);
+        for (int b = 0; b < 4; b++) xn[b] = *(const xv_t *)(xrow[b] + kn);
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -64,13 +93,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < 4; b++) xv[b] = xn[b];
     }
-    gemm_epilogue<EPI, 1, 4, false>(p, acc, n0, m0, frow, fgrp, false, nullptr);
+    if constexpr (AF32 && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16)) epilogue_f32_out<EPI>(p, acc, n0, m0, frow, fgrp);
+    else gemm_epilogue<EPI, 1, 4, false>(p, acc, n0, m0, frow, fgrp, false, nullptr);
 }
 
 template <int EPI>
 void launch_f32(const GemmParams & p, hipStream_t stream) {
     const int tiles = ((p.M + 63) / 64) * ((p.W.N + 63) / 64);
-    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(tiles), dim3(256), 0, stream, p);
+    if (p.act_f32) hipLaunchKernelGGL((gemm_f32_kernel<EPI, true>), dim3(tiles), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<EPI, false>), dim3(tiles), dim3(256), 0, stream, p);
 }
 
 }  // namespace

@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float * __restri
     const long src = in_rows ? (long)in_rows[r] : (long)r * in_row_mul;
     for (int c = threadIdx.x * 4; c < h; c += 256 * 4) {
         *(f4 *)(xp + (size_t)r * h + c) = *(const f4 *)(x + (size_t)src * h + c);
-        *(uint2 *)(ap + (size_t)r * h + c) = *(const uint2 *)(a + (size_t)src * h + c);
+        if (a) *(uint2 *)(ap + (size_t)r * h + c) = *(const uint2 *)(a + (size_t)src * h + c);      // (null: only the f32 rows)
     }
 }
 }  // namespace

@@ -117,6 +117,9 @@ struct GemmParams {
     // the caller runs other work on this device at the same time (the other tower of a two-tower step on a second stream): the heuristic then
     // keeps to the kernels that share a CU (two workgroups of <= 80 KB LDS) — see pick_tile in k_gemm.hip, round 6
     bool shared_device = false;
+    // f32 GGUF files (W_F32, k_gemm_f32.hip only; round 6): the activations between the kernels are f32 as in the reference (ggml f32 x f32): A is
+    // float [M][lda] behind the half_t pointer, and the fp16-output epilogues (EPI_F16 / EPI_GELU_F16 / EPI_QGELU_F16) store float [M][ldc]
+    bool act_f32 = false;
 };
 
 // tile: 0 = heuristic, else [ksplit*1000000 +] BM*1000 + BN  (BM in {64,128,160,192}, BN in {64,128}; ksplit only with BM = 64 / 65;
@@ -223,6 +226,11 @@ void launch_layernorm_prep(const float * x, int ldx, const float * w, const floa
 // seq_start == nullptr, uniform length T.  out: [rows][h] fp16.
 bool launch_attention(const half_t * qkv, half_t * out, int nseq, int T_uniform, const int * seq_start, int max_len,
                       int h, int n_head, bool causal, hipStream_t stream);
+
+// The same attention in f32 for f32 GGUF files (k_attn_f32.hip; the reference's KQ, soft_max and KQV are f32 for every file type): qkv float [rows][3h]
+// with Q pre-scaled, out float [rows][h]; any sequence length, d_head <= 128 and a multiple of 4.
+bool launch_attention_f32(const float * qkv, float * out, int nseq, int T_uniform, const int * seq_start, int max_len,
+                          int h, int n_head, bool causal, hipStream_t stream);
 
 // im2col for the stride-P patch convolution (reference clip.cpp:1309; ggml conv_2d im2col, fp16):
 // imgs [B][S][S][3] interleaved, f32 or (imgs_f16) already rounded to fp16 -> col [B*Np][Kpad] fp16, k = (c*P + ky)*P + kx, zero padded.

@@ -626,6 +626,8 @@ clip_ctx * load_model(const char * fname, int verbosity, int device) {
         ctx->ln_fold_force = e && e[0] == '2';       // tuning: fold even where forward.cpp fold_pays() says the LayerNorm launches are cheaper
         const char * e2 = getenv("CLIP_AMD_RESIDENT_PANELS");
         ctx->resident_panels_on = !(e2 && e2[0] == '0');
+        const char * ef = getenv("CLIP_AMD_F32_ACTS");
+        ctx->f32_acts = !(ef && ef[0] == '0');
         const char * ep = getenv("CLIP_AMD_PRUNE_LAST");
         ctx->prune_last = !(ep && ep[0] == '0');
         const char * ec = getenv("CLIP_AMD_LNFOLD_CENTRE");
@@ -663,6 +665,7 @@ clip_ctx * sibling_context(clip_ctx * owner, int index) {
     c->weights_borrowed = true;
     c->owner = owner;
     c->ln_fold = owner->ln_fold; c->ln_fold_force = owner->ln_fold_force; c->ln_fold_centre = owner->ln_fold_centre; c->prune_last = owner->prune_last;
+    c->f32_acts = owner->f32_acts;
     c->resident_panels_on = owner->resident_panels_on;           // (the table itself is the OWNER's: forward.cpp resident_panels — read-only, same device)
     c->graphs_enabled = false;                                   // (its launches are captured into the OWNER's graphs)
     c->split_min = c->split_max = 0;                             // (a sibling never splits)

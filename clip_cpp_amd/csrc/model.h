@@ -135,6 +135,7 @@ struct clip_ctx {
     bool weights_borrowed = false;   // this IS a sibling: weights_base belongs to the owner
     clip_ctx * owner = nullptr;      // (sibling only) the context whose captured graphs hold pointers into this one's workspace
     bool last_launch_split = false;  // vision_forward_launch: the last call ran as parts on this context and its sibling(s)
+    bool f32_acts = true;            // f32 GGUF files: f32 activations between the kernels (forward.cpp acts_f32); CLIP_AMD_F32_ACTS=0 at load: the fp16 form of round 5
     bool device_shared = false;      // clip_amd_set_device_shared: the caller runs other work on this device concurrently (kernels.h GemmParams::shared_device)
     bool sibling_busy = false;       // the sibling is carrying something else right now (the text tower of a two-tower multi call): no batch split
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
