@@ -126,13 +126,48 @@ __device__ __forceinline__ WFrag<WT> block_word(const RawBlock<WT> & r, int j) {
 // Activations of the FFN-up epilogue.  The result is rounded to fp16 right after, so the reciprocal is the hardware
 // v_rcp_f32 (1 ulp) instead of an IEEE division sequence (~10 instructions per element; at 96 outputs per thread the
 // epilogue was ~6 % of a K = 768 tile's time).  The reference evaluates both through fp16 lookup tables.
+// Round 6: the constants of the exponent are folded by hand (the build has no fast-math: __expf(a x) was v_mul (a x), v_mul (log2 e), v_exp) and the
+// last two operations are one FMA — 7 / 5 VALU instructions per output instead of 10 / 6: the FFN-up epilogue is VALU-issue-bound work next to a
+// co-resident K loop.  -DCLIPAMD_GELU_R5: the old expressions.
+//
+// GELU_SCALAR_FENCE — a correctness fence, not tuning.  With the two-FMA ln_apply below, hipcc's SLP vectoriser packed the whole strip
+// (v_pk_fma_f32 -> v_exp_f32 / v_rcp_f32 -> v_pk_mul_f32 on the reciprocals, one independent instruction after the second v_rcp_f32), and on
+// gfx950 / ROCm 7.2 that code returned wrong values on single quarter-waves (16 rows x 1 column of a fragment) a few dozen times per 2 M
+// outputs, differently from run to run: the text tower's FFN-up at 1027 rows showed it first (profiles/r06_experiments.txt section 8:
+// the same source with -fno-slp-vectorize, or with this fence, is bit-stable; barriers, s_sleep and s_nop around the epilogue are not a cure,
+// a plain v_exp_f32 whose source register the next VALU overwrites is fine — scripts/ubench/trans_war.hip).  The empty asm pins the
+// reciprocal and x as scalar values, so no packed instruction consumes a transcendental's result within the hazard recogniser's one wait
+// state; tests/test_gpu_kernels.py::test_activation_epilogues_are_bit_stable_run_to_run holds every kernel family to it.
+#define GELU_SCALAR_FENCE(t, x) asm volatile("" : "+v"(t), "+v"(x))
 __device__ __forceinline__ float gelu_tanh(float x) {
     // ggml_gelu_f32: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)));  0.5 (1 + tanh(u)) = 1 - 1/(exp(2u) + 1)
+#ifdef CLIPAMD_GELU_R5
     const float u = 0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x);
     const float e = __expf(2.0f * u);
     return x - x * __builtin_amdgcn_rcpf(e + 1.0f);
+#else
+    constexpr float C1 = 2.0f * 0.79788456080286535587989211986876f * 1.44269504088896340736f;   // exp(2u) = exp2(x (C1 + C2 x^2))
+    constexpr float C2 = C1 * 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, C2, C1));
+    float t = __builtin_amdgcn_rcpf(e + 1.0f);
+    GELU_SCALAR_FENCE(t, x);
+    float r = __builtin_fmaf(-x, t, x);
+    // ... and the result: where this FMA's only use is the fp16 conversion, hipcc fuses the two into v_fma_mixlo_f16 (ONE rounding) in some
+    // instantiations and not in others (57 / 25 of the ring kernel's 128- / 64-wide tiles): kernels then differ by an fp16 ulp on a few
+    // outputs per million.  Pinned, every kernel rounds to f32 and then to fp16.
+    asm volatile("" : "+v"(r));
+    return r;
+#endif
 }
-__device__ __forceinline__ float gelu_quick(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_quick(float x) {
+#ifdef CLIPAMD_GELU_R5
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+#else
+    float t = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.44269504088896340736f)));
+    GELU_SCALAR_FENCE(t, x);
+    return x * t;
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm folded into the GEMMs around it (kernels.h GemmParams::ln_* / xg_*).
@@ -355,10 +390,26 @@ __device__ __forceinline__ void resid_fold_tail(const GemmParams & p, f4 (&acc)[
 }
 
 // consumer half: v = acc + bias, or with the fold rstd_m (acc - mean_m c_n) + b'_n
-__device__ __forceinline__ f4 ln_apply(bool ln, const float2 & mr, const f4 & acc, const f4 & c, const f4 & bias) {
-    if (ln) return (acc - c * mr.x) * mr.y + bias;
-    return acc + bias;
+// Round 6: two FMAs per output — fma(acc, rstd q, fma(-c, mean rstd q, b' q)) — instead of mul, sub, mul, add and a multiply + select per output for the
+// Q scale q (clip.cpp:1363: after the bias; q = qscale on the Q columns, else 1: decided per 4-column strip, not per output).  The build runs
+// -ffp-contract=off, so the FMAs are spelled out: the fp16-output GEMMs of a ViT-B/32 batch spent ~10 % of their VALU instructions on the old forms
+// (+0.9 % on the two-tower step, profiles/r06_experiments.txt section 8).  Same algebra, fewer roundings; every kernel (k_skinny.hip restates it) uses
+// this form, so outputs stay bit-identical across kernels and tiles.  Without the fold: mr = (0, 1), c = 0 -> fma(acc, q, b q).
+__device__ __forceinline__ f4 ln_apply(const float2 & mr, float q, const f4 & acc, const f4 & c, const f4 & bias) {
+#ifdef CLIPAMD_LNAPPLY_R5              // A/B: the round-5 arithmetic (sub, mul, add, then the Q scale)
+    return ((acc - c * mr.x) * mr.y + bias) * q;
+#else
+    const float rq = mr.y * q, mq = mr.x * rq;
+    const f4 bq = bias * q;
+    f4 v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(acc[r], rq, __builtin_fmaf(-c[r], mq, bq[r]));
+    return v;
+#endif
 }
+// the Q scale of the 4 columns n .. n + 3 of an EPI_F16 strip (qcols is a multiple of 4 wherever it is set: h)
+template <int EPI>
+__device__ __forceinline__ float strip_qscale(const GemmParams & p, int n) { return (EPI == EPI_F16 && n < p.qcols) ? p.qscale : 1.0f; }
 
 // ---- epilogue.  D[i][j]: i = weight row n (row = 4*(lane>>4)+reg), j = activation row m (col = lane&15).
 // nbase / mbase: first weight row / activation row of this wave's sub-tile.
@@ -439,7 +490,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
             const int m = mbase + b * 16 + frow;
             if (m >= p.M) continue;
             f4 v;
-            if constexpr (LNE) v = ln_apply(ln, mr[b], acc[a][b], cv[a], bias);
+            if constexpr (LNE) v = ln_apply(mr[b], strip_qscale<EPI>(p, n), acc[a][b], ln ? cv[a] : (f4){0.f, 0.f, 0.f, 0.f}, bias);
+            else if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16)      // FOLD = false (k_gemm_f32.hip): same expression, no statistics
+                v = ln_apply(make_float2(0.f, 1.f), strip_qscale<EPI>(p, n), acc[a][b], (f4){0.f, 0.f, 0.f, 0.f}, bias);
             else v = acc[a][b] + bias;
             if constexpr (EPI == EPI_F32) {
                 *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
@@ -451,9 +504,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
                 const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
                 *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
             } else {
-                if constexpr (EPI == EPI_F16) {
-                    if (n < p.qcols) v = v * p.qscale;
-                } else if constexpr (EPI == EPI_GELU_F16) {
+                if constexpr (EPI == EPI_GELU_F16) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
                 } else if constexpr (EPI == EPI_QGELU_F16) {
@@ -504,7 +555,7 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
             const int m = mbase + b * 16 + frow;
             if (m >= p.M) continue;
             f4 v;
-            if constexpr (LNE) v = ln_apply(ln, mr[b], acc[a][b], cv[a], bias);
+            if constexpr (LNE) v = ln_apply(mr[b], strip_qscale<EPI>(p, n), acc[a][b], ln ? cv[a] : (f4){0.f, 0.f, 0.f, 0.f}, bias);
             else v = acc[a][b] + bias;
             if constexpr (EPI == EPI_F32) {
                 *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
@@ -515,9 +566,7 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmParams & p, f4 (&acc
                 const f4 pe = *(const f4 *)(p.pos + (size_t)(1 + pp) * p.ldc + n);
                 *(f4 *)((float *)p.out + ((size_t)img * p.T + 1 + pp) * p.ldc + n) = v + pe;
             } else {
-                if constexpr (EPI == EPI_F16) {
-                    if (n < p.qcols) v = v * p.qscale;
-                } else if constexpr (EPI == EPI_GELU_F16) {
+                if constexpr (EPI == EPI_GELU_F16) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
                 } else if constexpr (EPI == EPI_QGELU_F16) {
@@ -559,10 +608,8 @@ __device__ __forceinline__ void gemm_epilogue_f16_staged(const GemmParams & p, f
         const f4 bias = biasv[a];
 #pragma unroll
         for (int b = 0; b < TM; b++) {
-            f4 v = ln_apply(ln, mr[b], acc[a][b], cv[a], bias);
-            if constexpr (EPI == EPI_F16) {
-                if (n < p.qcols) v = v * p.qscale;
-            } else if constexpr (EPI == EPI_GELU_F16) {
+            f4 v = ln_apply(mr[b], strip_qscale<EPI>(p, n), acc[a][b], ln ? cv[a] : (f4){0.f, 0.f, 0.f, 0.f}, bias);
+            if constexpr (EPI == EPI_GELU_F16) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);
             } else if constexpr (EPI == EPI_QGELU_F16) {

@@ -267,13 +267,21 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
         const int n = n0 + fgrp * 4;
         const int m = m_base + b * 16 + frow;
         const bool ok = m < p.M && n < p.W.N;
-        if constexpr (FOLDC) {
-            if (foldc) {               // rstd (acc - mean c): (mean, rstd) of this lane's row, written before the barrier above
-                const float2 st = lnst[b * 16 + frow];
-                v = (v - c_pre * st.x) * st.y;
+        {
+            // bias / LayerNorm-fold consumer / Q scale exactly as the tiled kernels (gemm_common.h ln_apply, round 6: two FMAs per output, the Q scale
+            // folded into the coefficients of its 4-column strip); a wave finalises at most the one fragment row b == wave (MF <= NW)
+            const f4 bb = b == wave ? bias_pre : (f4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_QGELU_F16) {
+                float2 st = make_float2(0.f, 1.f);
+                f4 cc = (f4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (FOLDC) {
+                    if (foldc) { st = lnst[b * 16 + frow]; cc = c_pre; }     // (mean, rstd) of this lane's row, written before the barrier above
+                }
+                v = ln_apply(st, (EPI == EPI_F16 && n < p.qcols) ? p.qscale : 1.0f, v, cc, bb);
+            } else {
+                v = v + bb;
             }
         }
-        v = v + (b == wave ? bias_pre : (f4){0.f, 0.f, 0.f, 0.f});   // (MF <= NW: a wave finalises at most the one fragment row b == wave)
         if constexpr (EPI == EPI_F32) {
             if (ok) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = v;
         } else if constexpr (EPI == EPI_RESID_F32) {
@@ -310,7 +318,6 @@ __global__ void __launch_bounds__(NW * 64) skinny_kernel(const SkinnyParams p) {
             }
         } else {
             if constexpr (EPI == EPI_F16) {
-                if (n < p.qcols) v = v * p.qscale;
             } else if constexpr (EPI == EPI_GELU_F16) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gelu_tanh(v[r]);

@@ -19,6 +19,6 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm4.hip -o $V/k_gemm4.hip.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -Iinclude "$@" -c clip_cpp_amd/csrc/k_gemm32.hip -o $V/k_gemm32.hip.o &
 wait
-OBJS=$(ls $B/*.o | grep -v 'k_gemm')
+OBJS=$(ls $B/*.o | grep -v 'k_gemm_wt\|k_gemm\.hip\|k_gemm_ring\|k_gemm8\|k_gemm4\|k_gemm32')
 hipcc --offload-arch=gfx950 -shared -fPIC -o clip_cpp_amd/variants/libclip_$NAME.so $OBJS $V/*.o -lz -lpthread -ldl
 echo built clip_cpp_amd/variants/libclip_$NAME.so

@@ -25,7 +25,7 @@ for step in "$@"; do
     bench) if [ -z "${a1:-}" ]; then timeout 1200 python bench.py --json-out gpurun_out/${TAG}_bench.json 2>&1 | tail -1 | cut -c1-3000 | tee gpurun_out/${TAG}_bench.log
            else timeout 1200 python bench.py $(sp "$a1") 2>&1 | tail -1 | cut -c1-3000 | tee -a gpurun_out/${TAG}_bench_args.log; fi ;;
     ab) for r in $(seq 1 "$a1"); do for e in "$a2" "$a3"; do
-          envs=""; [ "$e" != "-" ] && envs="${e//,/ }"
+          envs=""; [ "$e" != "-" ] && envs="${e//,/ }"; envs="${envs//@/$PWD}"     # (@ = the repo root: CLIP_AMD_LIB=@/clip_cpp_amd/variants/libclip_X.so)
           echo -n "[$e] " | tee -a gpurun_out/${TAG}_ab.log
           env $envs timeout 900 python bench.py --steps 200 --warmup 20 $QUICK $(sp "${a4:-}") 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])" | tee -a gpurun_out/${TAG}_ab.log
         done; done ;;

@@ -742,3 +742,37 @@ def test_lnfold_small_m_kernels(L, tname, M, h, K1, N2, epi2):
     x1c, yc = run_lnfold(L, tid, raw1, h, K1, raw2, N2, A, b1, resid, g, beta, b2, epi2, 64128, 64128, 1, qc, qs)
     ab2 = np.abs(yb - yc) / (scale * 2.0 ** -10)
     assert ab2.max() <= 2.0, ab2.max()
+
+
+# ---- run-to-run bit stability of the activation epilogues (round 6) ----
+STABLE_TILES = [0, 64064, 64128, 65064, 65128, 128064, 128128, 160128, 192128, 160256, 256256, 256259, 256261, 320261]
+
+
+@pytest.mark.parametrize("tname", ["f16", "q4_0"])
+@pytest.mark.parametrize("epi", [2, 3, 1])
+def test_activation_epilogues_are_bit_stable_run_to_run(L, tname, epi):
+    """Round 6 regression.  A first version of the two-FMA epilogue let hipcc's SLP vectoriser pack the GELU chain (v_pk_fma_f32 -> v_exp /
+    v_rcp -> v_pk_mul_f32 on the reciprocals); on gfx950 that code returned wrong quarter-waves (16 rows x 1 column) a few dozen times per
+    2 M outputs, DIFFERENTLY from run to run — first seen on the text tower's FFN-up (1027 x 2048 x 512, ring kernel), invisible to every
+    accuracy bound (gemm_common.h GELU_SCALAR_FENCE).  Every kernel family: 6 runs of the same product, bit for bit, at that shape and at
+    one that reaches the large tiles; and inside the float64 bound."""
+    tid = ref.GGML_TYPES[tname]
+    for (M, N, K) in [(1027, 2048, 512), (4099, 3072, 768)]:
+        rng = np.random.default_rng(M + N + epi)
+        raw = ref.quantize(tid, _weights(rng, N, K))
+        Wd = ref.dequantize(tid, raw, N, K).astype(np.float64)
+        X = rng.standard_normal((M, K)).astype(np.float32)
+        bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        qc, qs = (N // 4, 0.125) if epi == 1 else (0, 1.0)
+        lin = _h(X).astype(np.float64) @ Wd.T + bias
+        want = {1: lin, 2: gelu_tanh(lin), 3: gelu_quick(lin)}[epi].copy()
+        want[:, :qc] *= qs
+        bound = 1.2e-3 * (np.abs(_h(X)).astype(np.float64) @ np.abs(Wd).T) + np.abs(want) * 2.0 ** -10 + 1e-4
+        for tile in STABLE_TILES:
+            if tile % 1000 == 261 and not (N >= 2 * K):
+                continue
+            base = run_gemm_ex(L, tid, raw, N, K, X, bias=bias, epi=epi, tile=tile, qcols=qc, qscale=qs)
+            assert np.all(np.abs(base - want) <= bound), (tile, M, N, K, float(np.abs(base - want).max()))
+            for _ in range(5):
+                y = run_gemm_ex(L, tid, raw, N, K, X, bias=bias, epi=epi, tile=tile, qcols=qc, qscale=qs)
+                assert np.array_equal(base, y), "tile %d (%d x %d x %d): %s" % (tile, M, N, K, _diff_report(base, y))

@@ -333,6 +333,22 @@ def test_last_layer_on_pooled_rows_only_matches_the_full_row_form(gpu, fixture_c
     np.testing.assert_allclose(got_t, ref_t, atol=atol)
 
 
+@pytest.mark.parametrize("ftype", ["q4_0", "f16"])
+def test_repeated_encodes_are_bit_identical(gpu, fixture_cache, ftype):
+    """Round 6 regression (gemm_common.h GELU_SCALAR_FENCE): the same batch through the same context, eager and graph replays, must return the
+    same bits — a mis-compiled activation epilogue made the ViT-B/32 text tower differ by up to 1 - cos = 8e-3 from run to run while staying
+    inside every oracle tolerance."""
+    p = fixtures.cached_model(fixture_cache, "b32", ftype)
+    imgs = fixtures.synthetic_images(21, 224, seed=5)
+    texts = _ragged_text_batch(24, fixtures.CONFIGS["b32"]["t"]["npos"], seed=4)
+    clip = gpu.Clip(p, device=0)
+    i0, t0 = clip.encode_images(imgs), clip.encode_texts(texts)
+    for _ in range(5):
+        assert np.array_equal(i0, clip.encode_images(imgs))
+        assert np.array_equal(t0, clip.encode_texts(texts))
+    clip.close()
+
+
 @pytest.mark.parametrize("config,ftype", [("g88", "f16"), ("g88", "q4_0"), ("g104", "q5_1"), ("g104", "f16")])
 def test_head_sizes_88_and_104_end_to_end(gpu, fixture_cache, config, ftype):
     """ViT-g/14 (d_head 88) and ViT-bigG/14 (d_head 104) head sizes, which the reference's generic graph accepts (clip.cpp:463-583, 1366-1388)
