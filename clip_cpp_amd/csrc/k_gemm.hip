@@ -494,6 +494,9 @@ int pick_tile(int M, int N, int Kpad, bool quantised, bool shared = false) {
     // Sustained (200 launches, profiles/r02_gemm8_experiments.txt section 11): l14.qkv 447 us vs 468 (160 x 256) / 485 (160 x 128),
     // l14.down 542 vs 579 / 607, l14.up 645 vs 652 / 705; at 32896 rows (batch 128): qkv 223 vs 238 / 241, down 287 vs 321 / 333,
     // out 110 vs 117 / 107, up 333 vs 332 / 360.  From two rounds of tiles up.
+    // (round 6: q/k/v and FFN-up of a ViT-L/14-class batch alone on the device on the 320 x 256 tile of k_gemm32.hip — isolated 494 / 677 us against
+    //  501 / 698 for the split below at 65792 rows, profiles/r06_experiments.txt section 5b; the residual GEMMs stay: 668 / 290 against 602 / 256)
+    if (!shared && !quantised && M >= 32768 && N >= 3 * Kpad && (N & 63) == 0 && Kpad >= 128 && wgs(320, 256) >= 3 * 256) return 320261;
     if (M >= 32768 && wgs(256, 256) >= 2 * 256) return 256260;
     // Round 6 — the wide fp16-output GEMMs of a ViT-B/32-class batch (q/k/v: N = 3 K, FFN-up: N = 4 K; 8192-32767 rows) on fp16 weights
     // (f16 files, or a resident panel of a block-quantised weight: forward.cpp resident_panels asks with quantised = false): the
@@ -606,7 +609,11 @@ void launch_gemm(const GemmParams & p0, int epilogue, int tile, hipStream_t stre
         p.W.wtype = W_F16;
         p.W.w16 = p.w16_pre;
     }
-    if (heuristic) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16, p.shared_device);
+    if (heuristic) {
+        tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16, p.shared_device);
+        // the 32 x 32 x 16 kernel carries the fp16-output epilogues only: any other launch of such a shape gets the choice made without it
+        if (tile % 1000 == 261 && !gemm32_supported(p, epilogue)) tile = pick_tile(p.M, p.W.N, p.W.Kpad, p.W.wtype != W_F16, true);
+    }
     if (tile % 1000 == 258 || tile % 1000 == 260) {
         // 256 x 256 tiles in whole rounds: one workgroup per CU means a launch costs ceil(tiles / 256) rounds, and ViT-L/14's
         // 65792 rows are 257 tile rows — one past a round boundary for every N.  The leading tile rows that fill whole rounds go to

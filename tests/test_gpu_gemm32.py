@@ -105,10 +105,12 @@ def test_gemm32_lnfold_consumer(L, tname, tile1, tile2, epi2, fold):
 
 
 def test_gemm32_at_the_baseline_shapes(L):
-    """q/k/v and FFN-up of the BASELINE batch (256 ViT-B/32 images = 12800 token rows; 10290 token rows of 256 texts): sampled rows of the
-    whole output against float64, and the heuristic sends these shapes here."""
+    """q/k/v and FFN-up of the BASELINE batch (256 ViT-B/32 images = 12800 token rows; 10290 token rows of 256 texts) and q/k/v of 130 ViT-L/14
+    images: sampled rows of the whole output against float64, and the heuristic sends these shapes here."""
     rng = np.random.default_rng(2026)
-    for (M, N, K, epi, tile) in [(12800, 2304, 768, 1, 256261), (12800, 3072, 768, 3, 320261), (10290, 1536, 512, 1, 256261), (10290, 2048, 512, 3, 320261)]:
+    assert L.clip_amd_test_gemm_tile(65792, 3072, 1024, 0) == 320261 and L.clip_amd_test_gemm_tile(65792, 4096, 1024, 0) == 320261     # ViT-L/14, batch 256, alone
+    for (M, N, K, epi, tile) in [(12800, 2304, 768, 1, 256261), (12800, 3072, 768, 3, 320261), (10290, 1536, 512, 1, 256261), (10290, 2048, 512, 3, 320261),
+                                 (33410, 3072, 1024, 1, 320261)]:
         tid = ref.GGML_TYPES["q4_0"]
         raw = ref.quantize(tid, _weights(rng, N, K))
         Wd = ref.dequantize(tid, raw, N, K)

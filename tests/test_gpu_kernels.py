@@ -693,7 +693,7 @@ def test_large_m_kernels_vs_float64_at_model_size(L, tname, M, N, K):
     four-wave tiles on the whole rounds + a second launch for the remaining rows (k_gemm4.hip), block-quantised weights through the
     fp16 panel — and the 8-wave 160 x 256 kernel, against the float64 product of the fp16-rounded activations with the dequantised
     weights, elementwise (bound = fp16 rounding of the dequantised weight), every row of the batch."""
-    assert L.clip_amd_test_gemm_tile(M, N, K, int(tname != "f16")) % 1000 in (259, 260)      # the regime under test
+    assert L.clip_amd_test_gemm_tile_ex(M, N, K, int(tname != "f16"), 1) % 1000 in (259, 260)      # the regime under test (f32 output: never k_gemm32.hip)
     rng = np.random.default_rng(M + N + K)
     tid = ref.GGML_TYPES[tname]
     raw = ref.quantize(tid, _weights(rng, N, K))

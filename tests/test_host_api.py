@@ -457,7 +457,7 @@ def test_gemm_tile_heuristic_covers_the_model_shapes(clip_lib):
     # round 6: q/k/v and FFN-up of a ViT-B/32-class batch alone on the device -> k_gemm32.hip, on the tile that fills its last round; not the narrow-round shapes
     assert tile(12800, 2304, 768, 0) == 256261 and tile(12800, 3072, 768, 0) == 320261 and tile(10290, 1536, 512, 0) == 256261
     assert tile(10290, 2048, 512, 0) % 1000 != 261 and tile(12800, 768, 768, 0) % 1000 != 261 and tile(12800, 768, 3072, 0) % 1000 != 261
-    assert tile(1600, 2304, 768, 0) % 1000 != 261 and tile(65792, 3072, 1024, 0) == 256260
+    assert tile(1600, 2304, 768, 0) % 1000 != 261 and tile(65792, 3072, 1024, 0) == 320261 and L.clip_amd_test_gemm_tile_ex(65792, 3072, 1024, 0, 1) == 256260
     for (M, N, K) in ((12800, 2304, 768), (12800, 3072, 768), (10290, 1536, 512)):
         assert L.clip_amd_test_gemm_tile_ex(M, N, K, 0, 1) == tile(M, N, K, 1) or L.clip_amd_test_gemm_tile_ex(M, N, K, 0, 1) // 1000 in (128, 160, 192)
     # <= 64 rows: the two-buffer 64 x 64 tile (the layers themselves run on k_skinny.hip there)
@@ -475,4 +475,4 @@ def test_gemm_tile_heuristic_covers_the_model_shapes(clip_lib):
     # batch 256 and beyond: never the ring
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         assert tile(12800, N, K) // 1000 in (128, 160, 192), (N, K, tile(12800, N, K))
-    assert tile(65792, 4096, 1024, 0) == 256260 and tile(65792, 1024, 4096, 0) == 256260                             # ViT-L/14 batch 256: four-wave 256 x 256
+    assert tile(65792, 4096, 1024, 0) == 320261 and L.clip_amd_test_gemm_tile_ex(65792, 4096, 1024, 0, 1) == 256260 and tile(65792, 1024, 4096, 0) == 256260                             # ViT-L/14 batch 256: four-wave 256 x 256
