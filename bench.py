@@ -821,7 +821,7 @@ def main():
         cosd = 1.0 - (got * want).sum(1)
         cpu_baseline = {"value": round((ns + nts) / cdt, 3), "unit": "embeddings/s", "cores": cores,
                         "kind": "port",
-                        "port_form": "SIMD integer dot products (%s, the shape of ggml's x86 vec_dot_q*_q8_*), cache-blocked over 32 activation rows; bit-identical to the scalar loop (tests/test_oracle_golden.py)" % ref.dot_simd_name(),
+                        "port_form": "SIMD integer dot products of the block-quantised mat-muls (%s; exact int32 block sums, the scalar loop's f32 operations in its order), cache-blocked; bit-identical to the scalar loop (tests/test_oracle_golden.py)" % ref.dot_simd_name(),
                         "sample": "%d images + %d texts of the same workload, oracle in ggml-faithful numerics (CPU restatement of the ggml path; ggml @dd1d575 unavailable; parity UNPINNED against ggml itself)" % (ns, nts),
                         "chunk4_threads4_images_per_s": round(c4, 3),
                         "chunk4_note": "reference harness form (tests/benchmark.cpp:50-51): batches of 4 images on 4 threads, %d images timed" % n4,

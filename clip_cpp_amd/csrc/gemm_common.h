@@ -400,10 +400,9 @@ __device__ __forceinline__ f4 ln_apply(const float2 & mr, float q, const f4 & ac
     return ((acc - c * mr.x) * mr.y + bias) * q;
 #else
     const float rq = mr.y * q, mq = mr.x * rq;
-    const f4 bq = bias * q;
     f4 v;
 #pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(acc[r], rq, __builtin_fmaf(-c[r], mq, bq[r]));
+    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(acc[r], rq, __builtin_fmaf(-c[r], mq, bias[r] * q));
     return v;
 #endif
 }

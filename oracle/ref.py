@@ -120,18 +120,18 @@ def dequantize(type_id, raw, nrows, k):
     return out
 
 
-DOT_SCALAR, DOT_AVX2, DOT_VNNI, DOT_BEST = 0, 1, 2, -1
+DOT_SCALAR, DOT_AVX2, DOT_VNNI, DOT_VNNI16, DOT_BEST = 0, 1, 2, 3, -1
 
 
 def set_dot_simd(form=DOT_BEST):
     """Form of the integer dot products of the block-quantised mul_mat (clip_oracle.cpp mul_mat_quant_simd): 0 scalar loop, 1 AVX2 vpmaddubsw,
-    2 AVX-512 VNNI vpdpbusd, -1 the best the CPU has (default).  Every form gives the same bits (tests/test_oracle_golden.py).  Returns the form in use."""
+    2 AVX-512 VNNI vpdpbusd (one dot product at a time), 3 AVX-512 VNNI with 16 output columns per register (no horizontal sums), -1 the best the CPU has (default).  Every form gives the same bits (tests/test_oracle_golden.py).  Returns the form in use."""
     return lib().orc_set_dot_simd(form)
 
 
 def dot_simd_name(form=None):
     form = set_dot_simd(DOT_BEST) if form is None else form
-    return {0: "scalar", 1: "AVX2 vpmaddubsw", 2: "AVX-512 VNNI vpdpbusd"}[form]
+    return {0: "scalar", 1: "AVX2 vpmaddubsw", 2: "AVX-512 VNNI vpdpbusd", 3: "AVX-512 VNNI vpdpbusd, 16 output columns per register"}[form]
 
 
 def mul_mat(type_id, raw, N, K, X, mode=MODE_FAITHFUL, n_threads=0):

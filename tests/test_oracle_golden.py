@@ -258,8 +258,8 @@ def test_integer_dot_path_equals_its_stated_arithmetic_bit_for_bit(tname, oracle
 @pytest.mark.parametrize("tname", ["q4_0", "q5_0", "q8_0", "q4_1", "q5_1"])
 def test_simd_integer_dot_forms_are_bit_identical_to_the_scalar_loop(tname, oracle_lib):
     """Round 6: the oracle's block-quantised mul_mat has a SIMD form of the integer dot products — vpmaddubsw + vpmaddwd
-    (AVX2, the shape of ggml's x86 vec_dot_q*_q8_*) and vpdpbusd (AVX-512 VNNI) — cache-blocked over 32 activation rows; bench.py's cpu_baseline
-    times it.  The integer sum of a block is exact in every form and the f32 accumulation over the blocks keeps the scalar path's order, so the
+    (AVX2, the shape of ggml's x86 vec_dot_q*_q8_*), vpdpbusd (AVX-512 VNNI) one dot product at a time, and vpdpbusd with 16 output columns per register
+    (weights interleaved and biased to unsigned, no horizontal sums: 4 x the scalar loop on a whole mat-mul) — cache-blocked; bench.py's cpu_baseline times the best.  The integer sum of a block is exact in every form and the f32 accumulation over the blocks keeps the scalar path's order, so the
     outputs must be the SAME BITS: odd shapes, several threads, saturating activations (|q| = 127) and a raw q8_0 weight byte of -128."""
     tid = ref.GGML_TYPES[tname]
     best = ref.set_dot_simd(ref.DOT_BEST)
