@@ -71,9 +71,30 @@ __device__ __forceinline__ uint32_t dequant_wpair(const WFrag<WT> & f, uint32_t 
             add = (h2){f.dm[1], f.dm[1]};
             sub = splat(1024.0f);
         }
-        uint32_t u = ((f.q >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
-        if constexpr (WT == W_Q5_0 || WT == W_Q5_1) u |= (hb >> s) & 0x00100010u;
-        h2 v = u2h(u) - sub;  // exact small integer
+        h2 v;
+#ifdef CLIPAMD_DEQUANT_R5
+        constexpr bool inplace = false;       // A/B: every pair through its own shift
+#else
+        constexpr bool inplace = WT == W_Q4_0 || WT == W_Q4_1;
+#endif
+        if constexpr (inplace) {
+            // round 6: the odd pairs (nibbles at bits 4-7 / 20-23 of the word shifted by 0 or 8) are taken IN PLACE — 0x6400 | (q << 4) is 1024 + 16 q, and
+            // fma(., 1/16, -(64 + zero)) = q - zero exactly — so a word costs one shift (by 8, shared by its pairs 2 and 3) instead of three:
+            // 13 VALU instructions per 8 weights instead of 15, same bits (every intermediate is an exact small integer)
+            const uint32_t w = s < 2 ? f.q : f.q >> 8;
+            if (s & 1) {
+                const uint32_t u = (w & 0x00F000F0u) | 0x64006400u;
+                const float z = WT == W_Q4_0 ? 72.0f : 64.0f;
+                v = __builtin_elementwise_fma(u2h(u), splat(0.0625f), splat(-z));
+            } else {
+                const uint32_t u = (w & 0x000F000Fu) | 0x64006400u;
+                v = u2h(u) - sub;  // exact small integer
+            }
+        } else {
+            uint32_t u = ((f.q >> (4 * s)) & 0x000F000Fu) | 0x64006400u;
+            if constexpr (WT == W_Q5_0 || WT == W_Q5_1) u |= (hb >> s) & 0x00100010u;
+            v = u2h(u) - sub;  // exact small integer
+        }
         if constexpr (WT == W_Q4_1 || WT == W_Q5_1) v = __builtin_elementwise_fma(v, scale, add);  // q*d + m, one rounding
         else v = v * scale;
         return h2u(v);
