@@ -22,6 +22,8 @@ $(OUT):
 # (-fwrapv: the file decoders run integer transforms over untrusted coefficients; same flag as clip_cpp_amd/build.py)
 $(OUT)/%.cpp.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) include/clip.h include/clip_amd.h | $(OUT)
 	$(HIPCC) -x hip -fwrapv $(CXXFLAGS) -c $< -o $@
+# (the f32-file kernels without the SLP vectoriser: same per-file flags as clip_cpp_amd/build.py EXTRA_FLAGS, which says why)
+$(OUT)/k_attn_f32.hip.o $(OUT)/k_gemm_f32.hip.o: CXXFLAGS += -fno-slp-vectorize
 $(OUT)/%.hip.o: $(SRC)/%.hip $(wildcard $(SRC)/*.h) | $(OUT)
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 $(OUT)/k_gemm_wt%.o: $(SRC)/k_gemm.hip $(wildcard $(SRC)/*.h) | $(OUT)

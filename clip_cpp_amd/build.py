@@ -25,6 +25,10 @@ HOST_SOURCES = ["gguf.cpp", "quant.cpp", "load.cpp", "forward.cpp", "tokenizer.c
                 "jpeg_decode.cpp", "host_pipeline.cpp", "api.cpp"]
 HIP_SOURCES = ["k_attn.hip", "k_attn_f32.hip", "k_misc.hip", "k_preproc.hip", "k_gemm.hip", "k_gemm8.hip", "k_gemm4.hip", "k_gemm32.hip", "k_gemm_f32.hip", "k_skinny.hip", "k_gemm_ring.hip", "k_fold.hip"]
 GEMM_WTYPES = [0, 1, 2, 3, 4, 5]
+# Per-file flags.  The f32-file kernels (a correctness path, not a tuned one) are built without the SLP vectoriser: packed f32 instructions that
+# consume a transcendental's result one wait state later are the suspect of the round-6 epilogue hazard (gemm_common.h GELU_SCALAR_FENCE,
+# profiles/r06_experiments.txt section 8), and hipcc forms exactly those around the online softmax of k_attn_f32.hip when it may.
+EXTRA_FLAGS = {"k_attn_f32.hip": ["-fno-slp-vectorize"], "k_gemm_f32.hip": ["-fno-slp-vectorize"]}
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-inline-asm", "-Wno-bitwise-instead-of-logical",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
@@ -72,7 +76,7 @@ def build(force=False, verbose=False):
         o = os.path.join(BUILD, src + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([cc, "--offload-arch=" + ARCH] + COMMON + ["-c", s, "-o", o])
+            jobs.append([cc, "--offload-arch=" + ARCH] + COMMON + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
     s = os.path.join(CSRC, "k_gemm.hip")
     for wt in GEMM_WTYPES:
         o = os.path.join(BUILD, "k_gemm_wt%d.o" % wt)

@@ -81,15 +81,23 @@ __global__ void __launch_bounds__(64) attn_f32_kernel(const float * __restrict__
             cmax = fmaxf(cmax, s[j]);
         }
         const float nm = fmaxf(mx, cmax);                // (key 0 is visible to every query: nm is finite from the first chunk on)
-        const float scale = __expf(mx - nm);             // exp(-inf) = 0 on the first chunk
+        float scale = __expf(mx - nm);                   // exp(-inf) = 0 on the first chunk
+        asm("" : "+v"(scale));                           // (kept a scalar value: o[] *= scale below would otherwise be packed right behind the v_exp_f32)                  // (transcendental results stay scalar values: gemm_common.h GELU_SCALAR_FENCE says why)
         mx = nm;
         sum *= scale;
 #pragma unroll
         for (int d = 0; d < DH; d++) o[d] *= scale;
+        // the exponentials of the whole chunk first (s[j] becomes p[j]), then the P V accumulation: written as one loop, hipcc packed the FMAs of
+        // adjacent output columns (v_pk_fma_f32) right behind each v_exp_f32 — the pattern behind the round-6 epilogue hazard (gemm_common.h
+        // GELU_SCALAR_FENCE); here every packed consumer is KC exponentials away from its operand
 #pragma unroll
         for (int j = 0; j < KC; j++) {
-            const float pj = __expf(s[j] - nm);          // masked keys: exp(-inf) = 0
-            sum += pj;
+            s[j] = __expf(s[j] - nm);                    // masked keys: exp(-inf) = 0
+            sum += s[j];
+        }
+#pragma unroll
+        for (int j = 0; j < KC; j++) {
+            const float pj = s[j];
 #pragma unroll
             for (int d = 0; d < DH; d += 4) {
                 const f4v vv = *(const f4v *)&Vs[j][d];
