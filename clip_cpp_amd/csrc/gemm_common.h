@@ -82,12 +82,19 @@ __device__ __forceinline__ uint32_t dequant_wpair(const WFrag<WT> & f, uint32_t 
             // fma(., 1/16, -(64 + zero)) = q - zero exactly — so a word costs one shift (by 8, shared by its pairs 2 and 3) instead of three:
             // 13 VALU instructions per 8 weights instead of 15, same bits (every intermediate is an exact small integer)
             const uint32_t w = s < 2 ? f.q : f.q >> 8;
+            // (x & mask) | magic as ONE v_and_or_b32: a VOP3 instruction of gfx9 cannot carry a literal, so with compile-time constants hipcc emits
+            // v_and_b32 + v_or_b32 (two VOP2 with a literal each: 64 of the 136 dequantisation instructions of a K-step pair of the 160 x 128 kernel);
+            // made opaque — the mask in an SGPR, the magic in a VGPR, hoisted out of the loop as any loop-invariant value — it folds into one
+            uint32_t magic = 0x64006400u, mask = (s & 1) ? 0x00F000F0u : 0x000F000Fu;
+#ifndef CLIPAMD_DEQUANT_R5
+            asm("" : "+v"(magic));
+            asm("" : "+s"(mask));
+#endif
+            const uint32_t u = (w & mask) | magic;
             if (s & 1) {
-                const uint32_t u = (w & 0x00F000F0u) | 0x64006400u;
                 const float z = WT == W_Q4_0 ? 72.0f : 64.0f;
                 v = __builtin_elementwise_fma(u2h(u), splat(0.0625f), splat(-z));
             } else {
-                const uint32_t u = (w & 0x000F000Fu) | 0x64006400u;
                 v = u2h(u) - sub;  // exact small integer
             }
         } else {
