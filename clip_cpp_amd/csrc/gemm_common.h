@@ -546,6 +546,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams & p, f4 (&acc)[TN
     }
 }
 
+// ---- residual epilogue with the residual fragments already in registers (k_gemm8.hip, round 6: requested before the K loop, so the tile's f32 rows —
+// 40 % of the epilogue's memory traffic — cross the fabric under the MFMAs instead of after them).  Same expressions as gemm_epilogue: same bits.
+template <int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue_resid_pre(const GemmParams & p, f4 (&acc)[TN][TM], const f4 (&rpre)[TN][TM], int nbase, int mbase, int frow, int fgrp,
+                                                        half_t * stage, int lane) {
+    const int N = p.W.N;
+    __builtin_amdgcn_s_waitcnt(0x0070);                // (see gemm_epilogue)
+    f4 biasv[TN];
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        int n = nbase + a * 16 + fgrp * 4;
+        n = n < N ? n : 0;
+        biasv[a] = p.bias ? *(const f4 *)(p.bias + n) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int a = 0; a < TN; a++) {
+        const int n = nbase + a * 16 + fgrp * 4;
+        if (n >= N) continue;
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            const int m = mbase + b * 16 + frow;
+            acc[a][b] = rpre[a][b] + (acc[a][b] + biasv[a]);
+            if (m < p.M) *(f4 *)((float *)p.out + (size_t)m * p.ldc + n) = acc[a][b];
+        }
+    }
+    if (p.xg_out) resid_fold_tail<TN, TM>(p, acc, nbase, mbase, frow, fgrp, stage, lane);
+}
+
 // ---- the same epilogue with its operands already in registers (k_gemm_ring.hip): the bias vectors — and, for the residual epilogue,
 // the residual fragments — were requested before the K loop, so the tail of a workgroup that has its CU to itself does not wait out
 // a memory round trip per strip (measured there: 7 us of a 60 us kernel at 64 x 256 tiles).  Same expressions, same rounding.

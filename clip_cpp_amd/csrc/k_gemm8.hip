@@ -238,6 +238,27 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
         if (ln && tid < BM) ln_mine = ln_row_centred(p, m0 + tid < p.M ? m0 + tid : p.M - 1, n0 == 0);
         __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): said with the builtin so that hipcc's own counting restarts from zero
     }
+    // Residual epilogue (FFN-down of a ViT-B/32-class batch: 160 x 256 tiles): the tile's f32 residual rows are requested HERE, before the first
+    // operand request — older than every LDS-DMA request, so the counted waits of the loop mean what they say — and arrive under the K loop.
+    // 80 registers beside the kernel's 172 (two waves per SIMD: 256); the 256-row tile has none to spare and keeps the one-strip-ahead fetch.
+#ifdef CLIPAMD_G8_NO_RPRE
+    constexpr bool RPRE = false;
+#else
+    constexpr bool RPRE = EPI == EPI_RESID_F32 && TM <= 5;
+#endif
+    f4 rpre[RPRE ? TN : 1][RPRE ? TM : 1];
+    if constexpr (RPRE) {
+#pragma unroll
+        for (int a = 0; a < TN; a++) {
+            int n = n0 + wn * 64 + a * 16 + fgrp * 4;
+            n = n < p.W.N ? n : 0;
+#pragma unroll
+            for (int b = 0; b < TM; b++) {
+                const int m = m0 + wm * TM * 16 + b * 16 + frow;
+                rpre[a][b] = *(const f4 *)(p.resid + (size_t)(m < p.M ? m : p.M - 1) * p.ldc + n);
+            }
+        }
+    }
     ISSUE_W(0, 0);
     ISSUE_X(0, 0);
     if (S == 3 && T > 1) {
@@ -288,6 +309,10 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(const GemmParams p) {
             gemm_epilogue_f16_staged<EPI, TN, TM>(p, acc, nb, mb, frow_e, fgrp_e, stage, lane_i, ln, rs_lane);
             done = true;
         }
+    }
+    if constexpr (RPRE) {
+        gemm_epilogue_resid_pre<TN, TM>(p, acc, rpre, nb, mb, frow_e, fgrp_e, stage, lane_i);
+        done = true;
     }
     if (!done) gemm_epilogue<EPI, TN, TM>(p, acc, nb, mb, frow_e, fgrp_e, ln, rs_lane, stage, lane_i);
 #ifdef CLIPAMD_G8_TIMING
