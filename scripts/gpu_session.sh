@@ -5,7 +5,8 @@
 #   tests[:pytest+args]        GPU test tier (default: tests/ -m gpu)
 #   smoke                      __graft_entry__.smoke()
 #   bench[:bench.py+args]      bench.py (JSON line kept as gpurun_out/TAG_bench.json when no args are given)
-#   ab:ROUNDS:ENV_A:ENV_B[:bench+args]   interleaved same-box A/B of two environment settings (VAR=value,VAR2=value; '-' = none) on bench.py
+#   ab:ROUNDS:ENV_A:ENV_B[:bench+args]   interleaved same-box A/B of two environment settings (VAR=value,VAR2=value; '-' = none; values cannot hold ',' or ':' —
+#                              CLIP_AMD_TILE_OVERRIDE lists need a hand-written loop) on bench.py
 #   gemm:gemm_bench.py+args    isolated GEMM timings (scripts/gemm_bench.py)
 #   stamps:VARIANT:gemm+args   per-workgroup phase stamps of a -DCLIPAMD_G8_TIMING variant library (scripts/build_variant.sh) -> scripts/g32_stamps.py
 #   round                      scripts/gpu_round.sh TAG (tests + smoke + bench + rocprofv3 traces + PMC passes)
