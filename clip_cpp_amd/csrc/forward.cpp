@@ -506,6 +506,7 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
     const DevLayer & l0 = tw.layers[0];
     unsigned want = 0;
     if (l0.ff2.wtype != W_F16 && l0.ff2.wtype != W_F32 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
+    if (l0.o.wtype != W_F16 && l0.o.wtype != W_F32 && rows >= 4096 && rows < 32768 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.o.N, l0.o.Kpad, false))) want |= 2u;
     // round 6: q/k/v and FFN-up where the 32 x 32 x 16 kernel (k_gemm32.hip: fp16 x fp16) takes the shape (ViT-B/32 at batch 256: 99 MB per tower)
     if (l0.qkv.wtype != W_F16 && l0.qkv.wtype != W_F32 && gemm_tile_for(rows, l0.qkv.N, l0.qkv.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 1u;
     if (l0.ff1.wtype != W_F16 && l0.ff1.wtype != W_F32 && gemm_tile_for(rows, l0.ff1.N, l0.ff1.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 4u;

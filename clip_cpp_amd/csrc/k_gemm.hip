@@ -514,6 +514,10 @@ int pick_tile(int M, int N, int Kpad, bool quantised, bool shared = false) {
         const int t = five ? t5 : t4;
         if ((float)t >= 0.8f * (float)(((t + 255) / 256) * 256)) return five ? 320261 : 256261;
     }
+    // Round 6: the out-projection (N = K) of a ViT-B/32-class batch on fp16 weights (f16 file or resident panel: forward.cpp resident_panels) on the 8-wave
+    // 160 x 256 kernel, whose residual rows are requested before its K loop: one round of 240 workgroups whose memory-bound epilogue phase is 40 % shorter —
+    // +1.0 ... +1.3 % on the two-tower step against the two-per-CU tile (profiles/r06_experiments.txt section 14)
+    if (!quantised && M >= 8192 && M < 32768 && N == Kpad && Kpad >= 512 && wgs(160, 256) >= 200 && wgs(160, 256) <= 256) return 160256;
     {
         const int t8 = wgs(160, 256);
         const float rounds = (float)t8 / 256.f;
