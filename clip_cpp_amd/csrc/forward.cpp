@@ -508,8 +508,12 @@ const half_t * const * resident_panels(clip_ctx * ctx, const DevTower & tw, int 
     if (l0.ff2.wtype != W_F16 && l0.ff2.wtype != W_F32 && rows >= 4096 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.ff2.N, l0.ff2.Kpad, false))) want |= 8u;
     if (l0.o.wtype != W_F16 && l0.o.wtype != W_F32 && rows >= 4096 && rows < 32768 && gemm_tile_uses_panel(gemm_tile_for(rows, l0.o.N, l0.o.Kpad, false))) want |= 2u;
     // round 6: q/k/v and FFN-up where the 32 x 32 x 16 kernel (k_gemm32.hip: fp16 x fp16) takes the shape (ViT-B/32 at batch 256: 99 MB per tower)
-    if (l0.qkv.wtype != W_F16 && l0.qkv.wtype != W_F32 && gemm_tile_for(rows, l0.qkv.N, l0.qkv.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 1u;
-    if (l0.ff1.wtype != W_F16 && l0.ff1.wtype != W_F32 && gemm_tile_for(rows, l0.ff1.N, l0.ff1.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 4u;
+    // ... from 32768 rows only (ViT-L/14 / H/14 batches, where the alternative is a per-layer dequantisation launch + the 256 x 256 kernel).  Below that
+    // (ViT-B/32-class batches) the fused-dequant two-per-CU kernels, after the instruction trims of round 6, are ahead of the 32 x 32 x 16 kernel on 99 MB of
+    // resident panels for block-quantised files: 80.5-80.6 k against 79.0-79.3 k img/s, texts 161 k against 163 k (profiles/r06_experiments.txt section 19);
+    // f16 files, which need no panel, keep that kernel (+2 %).
+    if (rows >= 32768 && l0.qkv.wtype != W_F16 && l0.qkv.wtype != W_F32 && gemm_tile_for(rows, l0.qkv.N, l0.qkv.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 1u;
+    if (rows >= 32768 && l0.ff1.wtype != W_F16 && l0.ff1.wtype != W_F32 && gemm_tile_for(rows, l0.ff1.N, l0.ff1.Kpad, false, device_shared(ctx)) % 1000 == 261) want |= 4u;
     if (!want) return nullptr;
     auto & tab = ctx->res_panels[which];
     if ((ctx->res_panel_mask[which] & want) == want && tab.size() == 4 * tw.layers.size()) return tab.data();

@@ -394,19 +394,33 @@ def test_resident_ffn_down_panels_do_not_change_a_bit(gpu, fixture_cache, monkey
     assert any(k.startswith("gemm8_kernel") and "ffn_down" in k for k in rep), sorted(rep)      # the panel kernel carries FFN-down
     assert not any(k.startswith("gemm32_kernel") for k in rep), sorted(rep)
     assert np.array_equal(first, want) and np.array_equal(run(c1), want)
-    # round 6: alone on the device, q/k/v and FFN-up also get resident panels and run on the 32 x 32 x 16 kernel (k_gemm32.hip): another k order
-    # inside the MFMA -> the embeddings agree to f32 rounding of the sums, not bit for bit; back on a shared device the bits return
+    # round 6: alone on the device a block-quantised ViT-B/32-class batch stays on the same kernels (the 32 x 32 x 16 kernel on resident q/k/v and FFN-up panels
+    # was measured behind the trimmed fused-dequant kernels: 79.0-79.3 k against 80.5-80.6 k img/s) -> the same bits
     c1.set_device_shared(False)
     c1.profile(True)
     alone = run(c1)
     rep = c1.profile_report(reset=True)
     c1.profile(False)
-    assert any(k.startswith("gemm32_kernel<4,4,1>") and "qkv" in k for k in rep) and any(k.startswith("gemm32_kernel<5,4,") and "ffn_up" in k for k in rep), sorted(rep)
-    assert float(one_minus_cos(alone, want).max()) <= 1e-6, float(one_minus_cos(alone, want).max())
-    assert np.array_equal(run(c1), alone)                                      # deterministic
-    c1.set_device_shared(True)
-    assert np.array_equal(run(c1), want)
+    assert not any(k.startswith("gemm32_kernel") for k in rep), sorted(rep)
+    assert np.array_equal(alone, want)
     c1.close()
+    # ... an f16 file (no panel to build) does take that kernel for q/k/v and FFN-up when it has the device to itself: another k order inside the MFMA ->
+    # the embeddings agree to f32 rounding of the sums, not bit for bit; deterministic; back on a shared device the bits return
+    p16 = fixtures.cached_model(fixture_cache, "b32", "f16", text=False, vision=True)
+    c2 = gpu.Clip(p16, device=0)
+    c2.set_device_shared(True)
+    want16 = run(c2)
+    c2.set_device_shared(False)
+    c2.profile(True)
+    alone16 = run(c2)
+    rep = c2.profile_report(reset=True)
+    c2.profile(False)
+    assert any(k.startswith("gemm32_kernel<4,4,1>") and "qkv" in k for k in rep) and any(k.startswith("gemm32_kernel<5,4,") and "ffn_up" in k for k in rep), sorted(rep)
+    assert float(one_minus_cos(alone16, want16).max()) <= 1e-6, float(one_minus_cos(alone16, want16).max())
+    assert np.array_equal(run(c2), alone16)                                    # deterministic
+    c2.set_device_shared(True)
+    assert np.array_equal(run(c2), want16)
+    c2.close()
 
 
 @pytest.mark.parametrize("config,ftype,B,rule", [("b32", "q4_0", 32, "2,64"), ("b32", "q4_0", 33, "2,64"), ("tiny14", "f16", 12, "2,64"), ("b32", "f16", 8, "2,64"),
